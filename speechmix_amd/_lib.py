@@ -1,0 +1,75 @@
+"""ctypes binding of libspeechmix_hip.so (the C-ABI drop-in boundary, see include/speechmix_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol is absent this module
+raises, and every op wrapper raises RuntimeError on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspeechmix_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+class RowView(C.Structure):
+    _fields_ = [("batch_stride", C.c_longlong), ("ld", C.c_longlong), ("off", C.c_longlong),
+                ("rows_per_batch", C.c_int), ("_pad", C.c_int)]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+                ("resid", C.c_void_p), ("aux_out", C.c_void_p), ("aux_in", C.c_void_p),
+                ("a", RowView), ("b", RowView), ("c", RowView),
+                ("batch_a", C.c_longlong), ("batch_b", C.c_longlong), ("batch_c", C.c_longlong),
+                ("batch_bias", C.c_longlong),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_rc", C.c_int), ("b_rc", C.c_int),
+                ("act", C.c_int), ("out_f32", C.c_int), ("atomic", C.c_int), ("nbatch", C.c_int),
+                ("split_k", C.c_int), ("tr_mode", C.c_int), ("alpha", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python speechmix_amd/csrc/build.py` "
+                "(speechmix_amd has no CPU or PyTorch fallback for its kernels)")
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"speechmix_hip: {name} failed with code {rc}")
+
+
+class NormParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("pos", C.c_void_p), ("xsum_out", C.c_void_p), ("y", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
+                ("rms", C.c_int), ("act", C.c_int), ("eps", C.c_float)]
+
+
+class NormBwdParams(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dres", C.c_void_p), ("dx", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dpos", C.c_void_p),
+                ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
+                ("rms", C.c_int), ("act", C.c_int)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p), ("lse", C.c_void_p),
+                ("bias", C.c_void_p), ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+                ("delta", C.c_void_p), ("dbias", C.c_void_p),
+                ("q_bs", C.c_longlong), ("q_ld", C.c_longlong), ("k_bs", C.c_longlong), ("k_ld", C.c_longlong),
+                ("v_bs", C.c_longlong), ("v_ld", C.c_longlong), ("o_bs", C.c_longlong), ("o_ld", C.c_longlong),
+                ("dq_bs", C.c_longlong), ("dq_ld", C.c_longlong), ("dk_bs", C.c_longlong), ("dk_ld", C.c_longlong),
+                ("dv_bs", C.c_longlong), ("dv_ld", C.c_longlong), ("do_bs", C.c_longlong), ("do_ld", C.c_longlong),
+                ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("D", C.c_int),
+                ("causal", C.c_int), ("scale", C.c_float)]

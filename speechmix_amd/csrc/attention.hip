@@ -1,0 +1,482 @@
+// Fused multi-head attention forward/backward for the SpeechMix hot path (gfx950).
+//   softmax(Q K^T * scale + bias [+ causal]) V, no padding mask (the reference never passes one:
+//   ref:speechmix/model.py:148, 135-136).  TF:models/wav2vec2/modeling_wav2vec2.py:466-548,
+//   TF:models/bart/modeling_bart.py:133-257 (self / causal / cross), TF:models/t5/modeling_t5.py:176-369
+//   (scale 1.0 + additive relative-position bias), TF:integrations/sdpa_attention.py:39-130.
+//
+// bf16 kernels (head_dim 64, every head on the path): flash-style, LDS-staged 64-row K/V (or Q/dO) tiles,
+// v_mfma_f32_16x16x32_bf16.  The score tile is produced TRANSPOSED (S^T = K Q^T) so each lane owns one
+// query column: softmax statistics are per-lane scalars and the exponentiated tile is already in the
+// B-operand layout of the following P·V product; the matching A operand (V^T, K^T, Q^T, dO^T) comes from
+// the row-major LDS tile through ds_read_b64_tr_b16.  No shuffles, no P round trip through LDS.
+// Backward = two kernels (dK/dV owner-computes over key tiles, dQ owner-computes over query tiles), both
+// recomputing S from the saved log-sum-exp: deterministic, no atomics.
+// fp32 kernels: simple one-thread-per-row loops (parity path / on-device cross-check).
+#include "smx_common.h"
+
+struct SmxAttnParams {
+    const void* Q; const void* K; const void* V;
+    void* O;
+    float* lse;           // [B, H, Tq]
+    const float* bias;    // optional [H, Tq, Tk] fp32 additive bias
+    const void* dO; void* dQ; void* dK; void* dV;   // backward only
+    float* delta;         // [B, H, Tq] backward scratch: sum_d dO*O
+    float* dbias;         // optional [H, Tq, Tk] fp32, atomically accumulated (fp32 path only)
+    long long q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld;       // element strides (batch, row)
+    long long dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, do_bs, do_ld;
+    int B, H, Tq, Tk, D;
+    int causal;
+    float scale;
+};
+
+#define NEG_BIG (-1e30f)
+
+// ============================== fp32 simple kernels ==============================================
+#define SIMPLE_MAXD 128
+__global__ void attn_fwd_f32(SmxAttnParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.B * p.H * p.Tq) return;
+    const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
+    const float* Q = reinterpret_cast<const float*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
+    const float* K = reinterpret_cast<const float*>(p.K) + b * p.k_bs + h * p.D;
+    const float* V = reinterpret_cast<const float*>(p.V) + b * p.v_bs + h * p.D;
+    float o[SIMPLE_MAXD];
+    for (int d = 0; d < p.D; ++d) o[d] = 0.f;
+    float m = NEG_BIG, l = 0.f;
+    const int kmax = p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk;
+    for (int k = 0; k < kmax; ++k) {
+        float s = 0.f;
+        for (int d = 0; d < p.D; ++d) s = fmaf(Q[d], K[k * p.k_ld + d], s);
+        s *= p.scale;
+        if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
+        const float mn = fmaxf(m, s);
+        const float a = expf(m - mn), e = expf(s - mn);
+        l = l * a + e;
+        for (int d = 0; d < p.D; ++d) o[d] = o[d] * a + e * V[k * p.v_ld + d];
+        m = mn;
+    }
+    float* O = reinterpret_cast<float*>(p.O) + b * p.o_bs + q * p.o_ld + h * p.D;
+    const float inv = 1.f / l;
+    for (int d = 0; d < p.D; ++d) O[d] = o[d] * inv;
+    p.lse[idx] = m + logf(l);
+}
+
+template <typename T>
+__global__ void attn_delta_kernel(SmxAttnParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.B * p.H * p.Tq) return;
+    const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
+    const T* O = reinterpret_cast<const T*>(p.O) + b * p.o_bs + q * p.o_ld + h * p.D;
+    const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + q * p.do_ld + h * p.D;
+    float s = 0.f;
+    for (int d = 0; d < p.D; d += 8) {
+        float a[8], c[8];
+        load8(O + d, a);
+        load8(dO + d, c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(a[e], c[e], s);
+    }
+    p.delta[idx] = s;
+}
+
+__global__ void attn_bwd_dq_f32(SmxAttnParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.B * p.H * p.Tq) return;
+    const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
+    const float* Q = reinterpret_cast<const float*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
+    const float* dO = reinterpret_cast<const float*>(p.dO) + b * p.do_bs + q * p.do_ld + h * p.D;
+    const float* K = reinterpret_cast<const float*>(p.K) + b * p.k_bs + h * p.D;
+    const float* V = reinterpret_cast<const float*>(p.V) + b * p.v_bs + h * p.D;
+    const float lse = p.lse[idx], delta = p.delta[idx];
+    float dq[SIMPLE_MAXD];
+    for (int d = 0; d < p.D; ++d) dq[d] = 0.f;
+    const int kmax = p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk;
+    for (int k = 0; k < kmax; ++k) {
+        float s = 0.f, dp = 0.f;
+        for (int d = 0; d < p.D; ++d) {
+            s = fmaf(Q[d], K[k * p.k_ld + d], s);
+            dp = fmaf(dO[d], V[k * p.v_ld + d], dp);
+        }
+        s *= p.scale;
+        if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
+        const float ds = expf(s - lse) * (dp - delta);
+        if (p.dbias) atomicAdd(p.dbias + ((long long)h * p.Tq + q) * p.Tk + k, ds);
+        for (int d = 0; d < p.D; ++d) dq[d] = fmaf(ds * p.scale, K[k * p.k_ld + d], dq[d]);
+    }
+    float* dQ = reinterpret_cast<float*>(p.dQ) + b * p.dq_bs + q * p.dq_ld + h * p.D;
+    for (int d = 0; d < p.D; ++d) dQ[d] = dq[d];
+}
+
+__global__ void attn_bwd_dkv_f32(SmxAttnParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.B * p.H * p.Tk) return;
+    const int k = idx % p.Tk, h = (idx / p.Tk) % p.H, b = idx / (p.Tk * p.H);
+    const float* Kp = reinterpret_cast<const float*>(p.K) + b * p.k_bs + k * p.k_ld + h * p.D;
+    const float* Vp = reinterpret_cast<const float*>(p.V) + b * p.v_bs + k * p.v_ld + h * p.D;
+    const float* Q = reinterpret_cast<const float*>(p.Q) + b * p.q_bs + h * p.D;
+    const float* dO = reinterpret_cast<const float*>(p.dO) + b * p.do_bs + h * p.D;
+    float dk[SIMPLE_MAXD], dv[SIMPLE_MAXD];
+    for (int d = 0; d < p.D; ++d) dk[d] = dv[d] = 0.f;
+    const int q0 = p.causal ? max(0, k - (p.Tk - p.Tq)) : 0;
+    for (int q = q0; q < p.Tq; ++q) {
+        float s = 0.f, dp = 0.f;
+        for (int d = 0; d < p.D; ++d) {
+            s = fmaf(Q[q * p.q_ld + d], Kp[d], s);
+            dp = fmaf(dO[q * p.do_ld + d], Vp[d], dp);
+        }
+        s *= p.scale;
+        if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
+        const long long li = ((long long)b * p.H + h) * p.Tq + q;
+        const float pr = expf(s - p.lse[li]);
+        const float ds = pr * (dp - p.delta[li]) * p.scale;
+        for (int d = 0; d < p.D; ++d) {
+            dv[d] = fmaf(pr, dO[q * p.do_ld + d], dv[d]);
+            dk[d] = fmaf(ds, Q[q * p.q_ld + d], dk[d]);
+        }
+    }
+    float* dK = reinterpret_cast<float*>(p.dK) + b * p.dk_bs + k * p.dk_ld + h * p.D;
+    float* dV = reinterpret_cast<float*>(p.dV) + b * p.dv_bs + k * p.dv_ld + h * p.D;
+    for (int d = 0; d < p.D; ++d) { dK[d] = dk[d]; dV[d] = dv[d]; }
+}
+
+// ============================== bf16 MFMA kernels (D = 64) =======================================
+// LDS tile: 64 rows x 64 bf16 (128-B rows), 16-B slots XOR-swizzled by (row>>1)&7 (conflict-free b128
+// fragment reads; 8-B tr-read granules stay intact).
+__device__ __forceinline__ int t_addr(int row, int d) {
+    return row * 128 + ((((d >> 3) ^ ((row >> 1) & 7)) << 4) | ((d & 7) << 1));
+}
+__device__ __forceinline__ uint2 tr_b64(const char* p) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    union { s16x4_t v; uint2 u; } r;
+    r.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
+    return r.u;
+}
+// stage a [64][64] bf16 tile (rows row0.. of a [T, ld] matrix, zero-filled past nrows); 256 threads
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* base, long long ld, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        const int r = (tid >> 3) + 32 * pss, c = tid & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(base + (long long)(row0 + r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(tile + t_addr(r, c * 8)) = v;
+    }
+}
+// KC fragment: lane (i = lane&15, g = lane>>4) gets row (r16+i), d = 32*kk + 8g .. +7
+__device__ __forceinline__ bf16x8_t frag_kc(const char* tile, int r16, int kk, int lane) {
+    union { bf16x8_t v; uint4 u; } f;
+    f.u = *reinterpret_cast<const uint4*>(tile + t_addr(r16 + (lane & 15), kk * 32 + (lane >> 4) * 8));
+    return f.v;
+}
+// transposed fragment for the "pair" reduction-slot mapping: k-slots e<4 -> row ra + 4g + e,
+// e>=4 -> row rb + 4g + (e-4); lane i = lane&15 receives column (c16 + i).
+__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int ra, int rb, int c16, int lane) {
+    const int i = lane & 15, g = lane >> 4, qq = i >> 2, c4 = (i & 3) * 4;
+    union { bf16x8_t v; uint2 h[2]; } f;
+    f.h[0] = tr_b64(tile + t_addr(ra + 4 * g + qq, c16 + c4));
+    f.h[1] = tr_b64(tile + t_addr(rb + 4 * g + qq, c16 + c4));
+    return f.v;
+}
+__device__ __forceinline__ bf16x8_t pack_pair(const f32x4_t& a, const f32x4_t& b) {
+    union { bf16x8_t v; unsigned u[4]; } f;
+    f.u[0] = pack_bf2(a[0], a[1]); f.u[1] = pack_bf2(a[2], a[3]);
+    f.u[2] = pack_bf2(b[0], b[1]); f.u[3] = pack_bf2(b[2], b[3]);
+    return f.v;
+}
+__device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups (same lane&15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+#define ZERO4 ((f32x4_t){0.f, 0.f, 0.f, 0.f})
+
+__global__ __launch_bounds__(256) void attn_fwd_bf16(SmxAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sK[8192];
+    __shared__ __attribute__((aligned(16))) char sV[8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int q = q0 + i16;                       // this lane's query column
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * 64;
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * 64;
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * 64;
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        union { bf16x8_t v; uint4 u; } f;
+        f.u = make_uint4(0, 0, 0, 0);
+        if (q < p.Tq) f.u = *reinterpret_cast<const uint4*>(Qp + (long long)q * p.q_ld + kk * 32 + g * 8);
+        qf[kk] = f.v;
+    }
+    f32x4_t o[4] = {ZERO4, ZERO4, ZERO4, ZERO4};
+    float m = NEG_BIG, l = 0.f;
+    const int coff = p.Tk - p.Tq;
+    int kend = p.Tk;
+    if (p.causal) kend = min(p.Tk, blockIdx.x * 64 + 64 + coff);   // keys beyond the block's last query are masked
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        __syncthreads();
+        stage_tile(sK, Kp, p.k_ld, k0, p.Tk, tid);
+        stage_tile(sV, Vp, p.v_ld, k0, p.Tk, tid);
+        __syncthreads();
+        f32x4_t s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = ZERO4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sK, t * 16, kk, lane), qf[kk], s[t], 0, 0, 0);
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + t * 16 + 4 * g + r;
+                float v = s[t][r] * p.scale;
+                if (p.bias && q < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + q) * p.Tk + key];
+                if (key >= p.Tk || (p.causal && key > q + coff)) v = -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = group_max(mx);
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[t][r] - mn);
+                s[t][r] = e;
+                rs += e;
+            }
+        l = l * alpha + group_sum(rs);
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {        // two 32-key reduction steps
+            const bf16x8_t pf = pack_pair(s[2 * st], s[2 * st + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, st * 32, st * 32 + 16, dt * 16, lane), pf,
+                                                                 o[dt], 0, 0, 0);
+        }
+    }
+    if (q < p.Tq) {
+        const float inv = 1.f / l;
+        bf16_t* Op = reinterpret_cast<bf16_t*>(p.O) + b * p.o_bs + (long long)q * p.o_ld + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 pk = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+            *reinterpret_cast<uint2*>(Op + dt * 16 + 4 * g) = pk;
+        }
+        if (g == 0) p.lse[((long long)b * p.H + h) * p.Tq + q] = m + __logf(l);
+    }
+}
+
+// dQ: block owns 64 queries (wave: 16), loops over key tiles.
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16(SmxAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sK[8192];
+    __shared__ __attribute__((aligned(16))) char sV[8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x * 64 + wave * 16 + i16;
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * 64;
+    const bf16_t* dOp = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * 64;
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * 64;
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * 64;
+    bf16x8_t qf[2], dof[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        union { bf16x8_t v; uint4 u; } f, d;
+        f.u = d.u = make_uint4(0, 0, 0, 0);
+        if (q < p.Tq) {
+            f.u = *reinterpret_cast<const uint4*>(Qp + (long long)q * p.q_ld + kk * 32 + g * 8);
+            d.u = *reinterpret_cast<const uint4*>(dOp + (long long)q * p.do_ld + kk * 32 + g * 8);
+        }
+        qf[kk] = f.v;
+        dof[kk] = d.v;
+    }
+    float lse = 0.f, delta = 0.f;
+    if (q < p.Tq) {
+        lse = p.lse[((long long)b * p.H + h) * p.Tq + q];
+        delta = p.delta[((long long)b * p.H + h) * p.Tq + q];
+    }
+    f32x4_t dq[4] = {ZERO4, ZERO4, ZERO4, ZERO4};
+    const int coff = p.Tk - p.Tq;
+    int kend = p.Tk;
+    if (p.causal) kend = min(p.Tk, blockIdx.x * 64 + 64 + coff);
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        __syncthreads();
+        stage_tile(sK, Kp, p.k_ld, k0, p.Tk, tid);
+        stage_tile(sV, Vp, p.v_ld, k0, p.Tk, tid);
+        __syncthreads();
+        f32x4_t ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4_t s = ZERO4, dp = ZERO4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sK, t * 16, kk, lane), qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sV, t * 16, kk, lane), dof[kk], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + t * 16 + 4 * g + r;
+                float v = s[r] * p.scale;
+                if (p.bias && q < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + q) * p.Tk + key];
+                float pr = __expf(v - lse);
+                if (key >= p.Tk || q >= p.Tq || (p.causal && key > q + coff)) pr = 0.f;
+                ds[t][r] = pr * (dp[r] - delta);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const bf16x8_t pf = pack_pair(ds[2 * st], ds[2 * st + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, st * 32, st * 32 + 16, dt * 16, lane), pf,
+                                                                  dq[dt], 0, 0, 0);
+        }
+    }
+    if (q < p.Tq) {
+        bf16_t* dQp = reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + (long long)q * p.dq_ld + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 pk = make_uint2(pack_bf2(dq[dt][0] * p.scale, dq[dt][1] * p.scale),
+                                  pack_bf2(dq[dt][2] * p.scale, dq[dt][3] * p.scale));
+            *reinterpret_cast<uint2*>(dQp + dt * 16 + 4 * g) = pk;
+        }
+    }
+}
+
+// dK/dV: block owns 64 keys (wave: 16), loops over query tiles.  Scores are produced UN-transposed here
+// (S = Q K^T: lane owns one key column) so that P and dS are again directly the B operand of the
+// reductions over queries.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(SmxAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sQ[8192];
+    __shared__ __attribute__((aligned(16))) char sDO[8192];
+    __shared__ float sLse[64];
+    __shared__ float sDelta[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, key = blockIdx.x * 64 + wave * 16 + i16;
+    const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * 64;
+    const bf16_t* dOp = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * 64;
+    const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * 64;
+    const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * 64;
+    bf16x8_t kf[2], vf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        union { bf16x8_t v; uint4 u; } f, d;
+        f.u = d.u = make_uint4(0, 0, 0, 0);
+        if (key < p.Tk) {
+            f.u = *reinterpret_cast<const uint4*>(Kp + (long long)key * p.k_ld + kk * 32 + g * 8);
+            d.u = *reinterpret_cast<const uint4*>(Vp + (long long)key * p.v_ld + kk * 32 + g * 8);
+        }
+        kf[kk] = f.v;
+        vf[kk] = d.v;
+    }
+    f32x4_t dk[4] = {ZERO4, ZERO4, ZERO4, ZERO4}, dv[4] = {ZERO4, ZERO4, ZERO4, ZERO4};
+    const int coff = p.Tk - p.Tq;
+    int qbeg = 0;
+    if (p.causal) qbeg = max(0, (int)(blockIdx.x * 64) - coff) & ~63;   // queries before this see none of the block's keys
+    for (int q0 = qbeg; q0 < p.Tq; q0 += 64) {
+        __syncthreads();
+        stage_tile(sQ, Qp, p.q_ld, q0, p.Tq, tid);
+        stage_tile(sDO, dOp, p.do_ld, q0, p.Tq, tid);
+        if (tid < 64) {
+            const int qq = q0 + tid;
+            sLse[tid] = qq < p.Tq ? p.lse[((long long)b * p.H + h) * p.Tq + qq] : 0.f;
+            sDelta[tid] = qq < p.Tq ? p.delta[((long long)b * p.H + h) * p.Tq + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x4_t pt[4], ds[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {          // 16-query sub-tiles: D rows = queries 4g+r, cols = keys
+            f32x4_t s = ZERO4, dp = ZERO4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sQ, t * 16, kk, lane), kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sDO, t * 16, kk, lane), vf[kk], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = t * 16 + 4 * g + r, qq = q0 + ql;
+                float v = s[r] * p.scale;
+                if (p.bias && qq < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + qq) * p.Tk + key];
+                float pr = __expf(v - sLse[ql]);
+                if (qq >= p.Tq || key >= p.Tk || (p.causal && key > qq + coff)) pr = 0.f;
+                pt[t][r] = pr;
+                ds[t][r] = pr * (dp[r] - sDelta[ql]);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {       // two 32-query reduction steps
+            const bf16x8_t pf = pack_pair(pt[2 * st], pt[2 * st + 1]);
+            const bf16x8_t df = pack_pair(ds[2 * st], ds[2 * st + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sDO, st * 32, st * 32 + 16, dt * 16, lane), pf,
+                                                                  dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, st * 32, st * 32 + 16, dt * 16, lane), df,
+                                                                  dk[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (key < p.Tk) {
+        bf16_t* dKp = reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + (long long)key * p.dk_ld + h * 64;
+        bf16_t* dVp = reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + (long long)key * p.dv_ld + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<uint2*>(dKp + dt * 16 + 4 * g) =
+                make_uint2(pack_bf2(dk[dt][0] * p.scale, dk[dt][1] * p.scale), pack_bf2(dk[dt][2] * p.scale, dk[dt][3] * p.scale));
+            *reinterpret_cast<uint2*>(dVp + dt * 16 + 4 * g) =
+                make_uint2(pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3]));
+        }
+    }
+}
+
+static int attn_check(const SmxAttnParams& p, int dtype) {
+    if (p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return SMX_EINVAL;
+    if (dtype == SMX_BF16 && p.D != 64) return SMX_EINVAL;
+    if (dtype == SMX_F32 && (p.D > SIMPLE_MAXD || (p.D & 7))) return SMX_EINVAL;
+    if (p.causal && p.Tk < p.Tq) return SMX_EINVAL;
+    return SMX_OK;
+}
+
+extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t stream) {
+    SmxAttnParams p = *pp;
+    int rc = attn_check(p, dtype);
+    if (rc) return rc;
+    if (dtype == SMX_F32) {
+        const int n = p.B * p.H * p.Tq;
+        hipLaunchKernelGGL(attn_fwd_f32, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+    } else if (dtype == SMX_BF16) {
+        hipLaunchKernelGGL(attn_fwd_bf16, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+    } else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t stream) {
+    SmxAttnParams p = *pp;
+    int rc = attn_check(p, dtype);
+    if (rc) return rc;
+    if (!p.delta || !p.dO || !p.dQ || !p.dK || !p.dV) return SMX_EINVAL;
+    const int n = p.B * p.H * p.Tq;
+    if (dtype == SMX_F32) {
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dq_f32, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+        const int nk = p.B * p.H * p.Tk;
+        hipLaunchKernelGGL(attn_bwd_dkv_f32, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
+    } else if (dtype == SMX_BF16) {
+        if (p.dbias) return SMX_EINVAL;
+        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dq_bf16, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+    } else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}

@@ -1,0 +1,373 @@
+// GEMM family for the SpeechMix hot path (gfx950).
+//
+//   C[m,n] (+)= epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// Each operand is either K-contiguous ("KC": logical [rows, K] row-major, rows addressed through a
+// SmxRowView so conv windows need no im2col) or rows-contiguous ("RC": logical [K, rows], i.e. the
+// reduction index is the slow one - dgrad's W[N,K] and both wgrad operands).  One kernel template
+// therefore covers fwd (KC,KC), dgrad (KC,RC) and wgrad (RC,RC) of every Linear / Conv1d on the path
+// (ref:speechmix/model.py:92-102, 148; TF:models/wav2vec2/modeling_wav2vec2.py:254-323, 466-572;
+//  TF:models/bart/modeling_bart.py:260-390).
+//
+// bf16 kernel: 128x128x64 tile, 4 waves (2x2, 64x64 each), v_mfma_f32_16x16x32_bf16 with the two
+// operands swapped so that each lane ends up owning 4 consecutive n of one m (8-byte epilogue
+// accesses).  KC tiles are XOR-swizzled 128-B rows read with ds_read_b128; RC tiles are [k][128]
+// images read with the gfx950 transposing read ds_read_b64_tr_b16.  Register-staged double-buffered
+// LDS, one barrier per K step.  fp32 kernel: a deliberately simple, independent VALU tile kernel
+// (parity path + on-device cross-check of the MFMA kernel).
+#include "smx_common.h"
+
+struct SmxGemmParams {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;      // [N] fp32 or null
+    const void* resid;      // same view as C (dtype = in dtype) or null: C += resid
+    void* aux_out;          // pre-activation copy (same view as C) or null
+    const void* aux_in;     // pre-activation of the consumer: C *= act'(aux_in) (same view as C) or null
+    SmxRowView a, b, c;
+    long long batch_a, batch_b, batch_c, batch_bias;  // element strides between grid.z batches
+    int M, N, K;
+    int a_rc, b_rc;
+    int act;                // SMX_ACT_* applied after bias (fwd) or used for aux_in derivative
+    int out_f32;            // C is fp32 regardless of input dtype
+    int atomic;             // C += via fp32 atomics (requires out_f32)
+    int nbatch, split_k;
+    int tr_mode;            // 1: ds_read_b64_tr_b16 for RC operands, 0: 16-bit LDS reads (debug/fallback)
+    float alpha;
+};
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define KC_TILE_BYTES (128 * 128)            // 128 rows x 64 bf16
+#define RC_TILE_BYTES (64 * 256)             // 64 k-rows x 128 bf16
+#define STAGE_BYTES (2 * 16384)
+
+__device__ __forceinline__ int kc_addr(int row, int chunk) {  // chunk: 16-B unit 0..7
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ int rc_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int rc_addr(int k, int col) {      // col: element 0..127
+    return k * 256 + ((((col >> 4) ^ rc_swz(k)) << 5) | ((col & 15) << 1));
+}
+
+// gfx950 transposing LDS read: within each 16-lane group the 16 lanes x 4 b16 addressed by the lanes
+// form a [4][16] block (lanes 4q..4q+3 supply row q); lane i receives column i (4 values, k = 0..3).
+__device__ __forceinline__ uint2 lds_tr_b64(const char* p) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    union { s16x4_t v; uint2 u; } r;
+    r.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
+    return r.u;
+}
+
+template <bool RC>
+struct TileLoader {
+    // per-thread staging: 4 x 16 B
+    uint4 r[4];
+    long long off[4];   // KC: element offset of my 4 rows (chunk added); RC: unused
+    bool ok[4];
+
+    __device__ __forceinline__ void init(const SmxRowView& v, int row0, int nrows, int tid) {
+        if (!RC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = row0 + (tid >> 3) + 32 * p;
+                ok[p] = row < nrows;
+                off[p] = view_off(v, ok[p] ? row : 0) + (tid & 7) * 8;
+            }
+        }
+    }
+    // KC: rows fixed, k advances.  RC: k-rows advance (view applied per k-row), cols fixed.
+    __device__ __forceinline__ void load(const bf16_t* base, const SmxRowView& v, int row0, int nrows, int k0, int K,
+                                         int tid) {
+        if (!RC) {
+            const int kk = k0 + (tid & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (ok[p] && kk < K) r[p] = *reinterpret_cast<const uint4*>(base + off[p] + k0);
+                else r[p] = make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const int col = row0 + (tid & 15) * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = k0 + (tid >> 4) + 16 * p;
+                if (k < K && col < nrows) r[p] = *reinterpret_cast<const uint4*>(base + view_off(v, k) + col);
+                else r[p] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+        if (!RC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<uint4*>(tile + kc_addr((tid >> 3) + 32 * p, tid & 7)) = r[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<uint4*>(tile + rc_addr((tid >> 4) + 16 * p, (tid & 15) * 8)) = r[p];
+        }
+    }
+};
+
+// fragment for the 16 rows starting at `r16` of the tile, K sub-step kk (0/1): 8 bf16 for k = 32kk+8g+e
+template <bool RC>
+__device__ __forceinline__ bf16x8_t load_frag(const char* tile, int r16, int kk, int lane, int tr_mode) {
+    const int i = lane & 15, g = lane >> 4;
+    union { bf16x8_t v; uint4 u; uint2 h[2]; bf16_t s[8]; } f;
+    if (!RC) {
+        f.u = *reinterpret_cast<const uint4*>(tile + kc_addr(r16 + i, kk * 4 + g));
+    } else if (tr_mode) {
+        // 16-lane group g reads a [4 k][16 col] block: lane supplies the 8-B address of (k = q, cols 4c..4c+3)
+        const int q = i >> 2, c4 = (i & 3) * 4;
+        const int kb = kk * 32 + 8 * g + q;
+        f.h[0] = lds_tr_b64(tile + rc_addr(kb, r16 + c4));
+        f.h[1] = lds_tr_b64(tile + rc_addr(kb + 4, r16 + c4));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            f.s[e] = *reinterpret_cast<const bf16_t*>(tile + rc_addr(kk * 32 + 8 * g + e, r16 + i));
+    }
+    return f.v;
+}
+
+template <typename TOUT>
+__device__ __forceinline__ void epilogue4(const SmxGemmParams& p, long long zc, long long zbias, int m, int n0,
+                                          float v[4]) {
+    // lane owns C[m, n0..n0+3]
+    if (m >= p.M || n0 >= p.N) return;
+    const long long base = zc + view_off(p.c, m) + n0;
+    const int nv = min(4, p.N - n0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < nv) {
+            float x = v[j] * p.alpha;
+            if (p.bias) x += p.bias[zbias + n0 + j];
+            if (p.aux_out) reinterpret_cast<bf16_t*>(p.aux_out)[base + j] = f2bf(x);
+            if (!p.aux_in) x = act_fwd(x, p.act);
+            else x *= act_grad(bf2f(reinterpret_cast<const bf16_t*>(p.aux_in)[base + j]), p.act);
+            if (p.resid) x += bf2f(reinterpret_cast<const bf16_t*>(p.resid)[base + j]);
+            v[j] = x;
+        }
+    }
+    if (p.out_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + base;
+        if (p.atomic) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nv) atomicAdd(c + j, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nv) c[j] = v[j];
+        }
+    } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + base;
+        if (nv == 4 && ((base & 3) == 0)) {
+            uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            *reinterpret_cast<uint2*>(c) = pk;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nv) c[j] = f2bf(v[j]);
+        }
+    }
+}
+
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware, bijective remap of the linear tile id: blocks b, b+8, b+16.. (same XCD, same L2) get
+    // consecutive tiles, which share the A row-panel.
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int tm = wg / ntn, tn = wg - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.z;
+    const int zb = z / p.split_k, zs = z - zb * p.split_k;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
+    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias;
+
+    // K range of this split (multiple of BK)
+    const int ksteps_total = (p.K + BK - 1) / BK;
+    const int per = (ksteps_total + p.split_k - 1) / p.split_k;
+    const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
+    if (ks0 >= ks1 && p.split_k > 1) return;
+
+    TileLoader<A_RC> la;
+    TileLoader<B_RC> lb;
+    la.init(p.a, m0, p.M, tid);
+    lb.init(p.b, n0, p.N, tid);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+
+    la.load(A, p.a, m0, p.M, ks0 * BK, p.K, tid);
+    lb.load(B, p.b, n0, p.N, ks0 * BK, p.K, tid);
+    la.store(smem, tid);
+    lb.store(smem + 16384, tid);
+    __syncthreads();
+
+    int cur = 0;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const bool more = ks + 1 < ks1;
+        if (more) {
+            la.load(A, p.a, m0, p.M, (ks + 1) * BK, p.K, tid);
+            lb.load(B, p.b, n0, p.N, (ks + 1) * BK, p.K, tid);
+        }
+        const char* tA = smem + cur * STAGE_BYTES;
+        const char* tB = tA + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_RC>(tA, wm * 64 + i * 16, kk, lane, p.tr_mode);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_RC>(tB, wn * 64 + j * 16, kk, lane, p.tr_mode);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    // swapped operands: D[row = n (4g+reg)][col = m (lane&15)]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            la.store(smem + (cur ^ 1) * STAGE_BYTES, tid);
+            lb.store(smem + (cur ^ 1) * STAGE_BYTES + 16384, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue4<bf16_t>(p, zc, zbias, m0 + wm * 64 + i * 16 + i16, n0 + wn * 64 + j * 16 + 4 * g, v);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32: simple 64x64x16 VALU tile kernel with fully generic operand addressing.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
+    __shared__ float As[16][65];
+    __shared__ float Bs[16][65];
+    const int tid = threadIdx.x;
+    const int ntn = (p.N + 63) / 64;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int z = blockIdx.z;
+    const int zb = z / p.split_k, zs = z - zb * p.split_k;
+    const float* A = reinterpret_cast<const float*>(p.A) + (long long)zb * p.batch_a;
+    const float* B = reinterpret_cast<const float*>(p.B) + (long long)zb * p.batch_b;
+    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias;
+    const int ksteps_total = (p.K + 15) / 16;
+    const int per = (ksteps_total + p.split_k - 1) / p.split_k;
+    const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
+    if (ks0 >= ks1 && p.split_k > 1) return;
+
+    const int tx = tid & 15, ty = tid >> 4;  // each thread: 4 m (ty*4..) x 4 n (tx*4..)
+    float acc[4][4] = {};
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int k0 = ks * 16;
+        // cooperative loads: 1024 elements per operand, 4 per thread
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;
+            {   // A tile element (r, k)
+                int r, k;
+                if (p.a_rc) { r = idx & 63; k = idx >> 6; } else { k = idx & 15; r = idx >> 4; }
+                float v = 0.f;
+                if (m0 + r < p.M && k0 + k < p.K)
+                    v = p.a_rc ? A[view_off(p.a, k0 + k) + m0 + r] : A[view_off(p.a, m0 + r) + k0 + k];
+                As[k][r] = v;
+            }
+            {
+                int r, k;
+                if (p.b_rc) { r = idx & 63; k = idx >> 6; } else { k = idx & 15; r = idx >> 4; }
+                float v = 0.f;
+                if (n0 + r < p.N && k0 + k < p.K)
+                    v = p.b_rc ? B[view_off(p.b, k0 + k) + n0 + r] : B[view_off(p.b, n0 + r) + k0 + k];
+                Bs[k][r] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= p.M) continue;
+        const long long rowb = zc + view_off(p.c, m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= p.N) continue;
+            float x = acc[i][j] * p.alpha;
+            if (p.bias) x += p.bias[zbias + n];
+            if (p.aux_out) reinterpret_cast<float*>(p.aux_out)[rowb + n] = x;
+            if (!p.aux_in) x = act_fwd(x, p.act);
+            else x *= act_grad(reinterpret_cast<const float*>(p.aux_in)[rowb + n], p.act);
+            if (p.resid) x += reinterpret_cast<const float*>(p.resid)[rowb + n];
+            float* c = reinterpret_cast<float*>(p.C) + rowb + n;
+            if (p.atomic) atomicAdd(c, x); else *c = x;
+        }
+    }
+}
+
+extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) {
+    SmxGemmParams p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K < 0) return SMX_EINVAL;
+    if (p.nbatch < 1) p.nbatch = 1;
+    if (p.split_k < 1) p.split_k = 1;
+    if (p.split_k > 1 && !p.atomic) return SMX_EINVAL;
+    if (p.atomic && !(p.out_f32 || dtype == SMX_F32)) return SMX_EINVAL;
+    if (dtype == SMX_F32) {
+        p.out_f32 = 1;
+        dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), 1, p.nbatch * p.split_k);
+        hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, p);
+        SMX_CHECK_LAUNCH();
+    }
+    if (dtype != SMX_BF16) return SMX_EINVAL;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
+    const size_t lds = 2 * STAGE_BYTES;
+    if (!p.a_rc && !p.b_rc)
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), lds, stream, p);
+    else if (!p.a_rc && p.b_rc)
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), lds, stream, p);
+    else if (p.a_rc && !p.b_rc)
+        hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), lds, stream, p);
+    SMX_CHECK_LAUNCH();
+}

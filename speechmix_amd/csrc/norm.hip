@@ -1,0 +1,225 @@
+// LayerNorm / RMSNorm forward + backward (HBM-bound, one wave per row, fp32 statistics, 16-B accesses).
+//   TF:models/wav2vec2/modeling_wav2vec2.py:429-434, 575-608 (LayerNorm eps=layer_norm_eps),
+//   TF:models/wav2vec2/modeling_wav2vec2.py:275-299 (conv -> LayerNorm over C -> GELU, "layer" extractor),
+//   TF:models/bart/modeling_bart.py:507-549 (x + positions -> layernorm_embedding),
+//   TF:models/t5/modeling_t5.py:50-72 (RMS norm: no mean, no bias).
+// Fusions: optional additive positional table (row r adds pos[(r % pos_period) + pos_offset]) with the
+// summed input written back for backward, optional activation after the affine, optional residual
+// gradient add in backward, gamma/beta gradients reduced per block and atomically added in fp32.
+// Requires D % 8 == 0 and D <= 1024 (every width on the path: 512, 768, 1024; tiny test widths 32/64).
+#include "smx_common.h"
+
+#define LN_NCH 2  // 8-element chunks per lane -> D <= 64 * 8 * 2
+
+struct SmxNormParams {
+    const void* x;        // [M, D] input (dtype T)
+    const void* pos;      // optional [*, D] table (dtype T) added to x
+    void* xsum_out;       // optional [M, D]: x + pos (dtype T)
+    void* y;              // [M, D]
+    const float* gamma;   // [D]
+    const float* beta;    // [D] or null (always null for rms)
+    float* mean;          // [M] (unused for rms)
+    float* rstd;          // [M]
+    int M, D;
+    int pos_period, pos_offset;
+    int rms;              // 1: RMS norm
+    int act;              // activation applied after affine
+    float eps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(SmxNormParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const T* x = reinterpret_cast<const T*>(p.x) + (long long)row * p.D;
+    const T* pos = p.pos ? reinterpret_cast<const T*>(p.pos) + (long long)((row % p.pos_period) + p.pos_offset) * p.D
+                         : nullptr;
+    T* xs = p.xsum_out ? reinterpret_cast<T*>(p.xsum_out) + (long long)row * p.D : nullptr;
+    float v[LN_NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        if (c < p.D) {
+            load8(x + c, v[j]);
+            if (pos) {
+                float t[8];
+                load8(pos + c, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[j][e] = rt(v[j][e] + t[e], x);
+            }
+            if (xs) store8(xs + c, v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];
+        }
+    }
+    const float invD = 1.0f / (float)p.D;
+    float mean = 0.f;
+    if (!p.rms) mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < p.D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invD + p.eps);
+    if (lane == 0) {
+        if (p.mean) p.mean[row] = mean;
+        if (p.rstd) p.rstd[row] = rstd;
+    }
+    T* y = reinterpret_cast<T*>(p.y) + (long long)row * p.D;
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < p.D) {
+            float o[8], gm[8], bt[8];
+            load8(p.gamma + c, gm);
+            if (p.beta) load8(p.beta + c, bt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[j][e] - mean) * rstd * gm[e];
+                if (p.beta) t += bt[e];
+                o[e] = act_fwd(t, p.act);
+            }
+            store8(y + c, o);
+        }
+    }
+}
+
+struct SmxNormBwdParams {
+    const void* dy;       // [M, D]
+    const void* x;        // [M, D] the normalised input (x + pos if that was fused)
+    const void* dres;     // optional [M, D]: added to dx (residual branch gradient)
+    void* dx;             // [M, D]
+    const float* gamma;
+    const float* beta;    // needed only when act != none
+    const float* mean;
+    const float* rstd;
+    float* dgamma;        // [D] fp32, accumulated atomically (or null)
+    float* dbeta;         // [D] or null
+    float* dpos;          // optional fp32 [*, D]: positional table gradient (atomic), same indexing as fwd
+    int M, D;
+    int pos_period, pos_offset;
+    int rms, act;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(SmxNormBwdParams p) {
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[j][e] = db[j][e] = gm[j][e] = bt[j][e] = 0.f;
+        if (c < p.D) {
+            load8(p.gamma + c, gm[j]);
+            if (p.beta && p.act != SMX_ACT_NONE) load8(p.beta + c, bt[j]);
+        }
+    }
+    const float invD = 1.0f / (float)p.D;
+    for (int row = blockIdx.x * 4 + w; row < p.M; row += nwaves) {
+        const T* x = reinterpret_cast<const T*>(p.x) + (long long)row * p.D;
+        const T* dy = reinterpret_cast<const T*>(p.dy) + (long long)row * p.D;
+        const float mean = p.rms ? 0.f : p.mean[row];
+        const float rstd = p.rstd[row];
+        float xh[LN_NCH][8], g[LN_NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_NCH; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            if (c < p.D) {
+                float xv[8], dv[8];
+                load8(x + c, xv);
+                load8(dy + c, dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xhat = (xv[e] - mean) * rstd;
+                    float d = dv[e];
+                    if (p.act != SMX_ACT_NONE) d *= act_grad(xhat * gm[j][e] + bt[j][e], p.act);
+                    dg[j][e] += d * xhat;
+                    db[j][e] += d;
+                    const float gg = d * gm[j][e];
+                    xh[j][e] = xhat;
+                    g[j][e] = gg;
+                    s1 += gg;
+                    s2 += gg * xhat;
+                }
+            }
+        }
+        s1 = p.rms ? 0.f : wave_sum(s1) * invD;
+        s2 = wave_sum(s2) * invD;
+        T* dx = reinterpret_cast<T*>(p.dx) + (long long)row * p.D;
+        const T* dres = p.dres ? reinterpret_cast<const T*>(p.dres) + (long long)row * p.D : nullptr;
+        float* dpos = p.dpos ? p.dpos + (long long)((row % p.pos_period) + p.pos_offset) * p.D : nullptr;
+#pragma unroll
+        for (int j = 0; j < LN_NCH; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            if (c < p.D) {
+                float o[8], r[8];
+                if (dres) load8(dres + c, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = (g[j][e] - s1 - xh[j][e] * s2) * rstd;
+                    if (dpos) atomicAdd(dpos + c + e, o[e]);
+                    if (dres) o[e] += r[e];
+                }
+                store8(dx + c, o);
+            }
+        }
+    }
+    if (!p.dgamma && !p.dbeta) return;
+    // block reduction of the per-wave column partials, then one atomic per column per block
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        if (64 * 8 * j >= p.D) break;
+        const int c = (lane + 64 * j) * 8;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float* dst = pass == 0 ? p.dgamma : p.dbeta;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[w][lane][e] = pass == 0 ? dg[j][e] : db[j][e];
+            __syncthreads();
+            if (w == 0 && c < p.D && dst) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    atomicAdd(dst + c + e, red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e]);
+            }
+        }
+    }
+}
+
+extern "C" int smx_norm_fwd(const SmxNormParams* pp, int dtype, hipStream_t stream) {
+    SmxNormParams p = *pp;
+    if (p.M <= 0 || p.D <= 0 || p.D > 64 * 8 * LN_NCH || (p.D & 7)) return SMX_EINVAL;
+    if (p.pos && p.pos_period <= 0) return SMX_EINVAL;
+    dim3 grid((p.M + 3) / 4);
+    if (dtype == SMX_F32) hipLaunchKernelGGL(norm_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
+    else if (dtype == SMX_BF16) hipLaunchKernelGGL(norm_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t stream) {
+    SmxNormBwdParams p = *pp;
+    if (p.M <= 0 || p.D <= 0 || p.D > 64 * 8 * LN_NCH || (p.D & 7)) return SMX_EINVAL;
+    if (p.dpos && p.pos_period <= 0) return SMX_EINVAL;
+    int blocks = (p.M + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    if (dtype == SMX_F32) hipLaunchKernelGGL(norm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
+    else if (dtype == SMX_BF16) hipLaunchKernelGGL(norm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}

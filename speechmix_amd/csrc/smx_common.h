@@ -1,0 +1,138 @@
+// speechmix_amd — common device helpers for gfx950 (CDNA4) kernels.
+// Wavefront = 64 lanes, MFMA 16x16x32 bf16, LDS-staged tiles.  No CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMX_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA 16x16x32 A/B operand (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// ---- error convention: launchers return 0 on success, hipError_t (>0) or negative arg errors ----
+#define SMX_OK 0
+#define SMX_EINVAL (-22)
+#define SMX_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        return e__ == hipSuccess ? SMX_OK : (int)e__;        \
+    } while (0)
+
+// ---- dtype tags used across the C ABI ----
+enum { SMX_F32 = 0, SMX_BF16 = 1 };
+
+// ---- bf16 <-> f32 ----
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // round-nearest-even
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Cvt<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---- 8-element vector access (16 B of bf16 / 32 B of fp32); pointers must be 16-B aligned ----
+__device__ __forceinline__ void load8(const bf16_t* p, float o[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void load8(const float* p, float o[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]),
+                                              pack_bf2(v[6], v[7]));
+}
+__device__ __forceinline__ void store8(float* p, const float v[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// round-trip through the storage type (so statistics see exactly what is stored)
+__device__ __forceinline__ float rt(float v, const bf16_t*) { return bf2f(f2bf(v)); }
+__device__ __forceinline__ float rt(float v, const float*) { return v; }
+
+// ---- activations (exact erf GELU as in HF ACT2FN["gelu"]) ----
+enum { SMX_ACT_NONE = 0, SMX_ACT_GELU = 1, SMX_ACT_RELU = 2 };
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    if (act == SMX_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (act == SMX_ACT_RELU) return x > 0.f ? x : 0.f;
+    return x;
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+    if (act == SMX_ACT_GELU) {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+        return cdf + x * pdf;
+    }
+    if (act == SMX_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// ---- wave / block reductions (64-wide) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `sh` needs 16 floats
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+// ---- row view: maps a logical row index to an element offset.  Lets a GEMM operand be an
+// overlapping / strided window over a [batch, time, channel] activation (conv as GEMM without im2col).
+struct SmxRowView {
+    long long batch_stride;  // elements between consecutive batches
+    long long ld;            // elements between consecutive rows inside a batch
+    long long off;           // constant element offset
+    int rows_per_batch;      // logical rows per batch (<=0: single batch)
+    int _pad;
+};
+__device__ __forceinline__ long long view_off(const SmxRowView& v, int r) {
+    if (v.rows_per_batch > 0) {
+        const int b = r / v.rows_per_batch;
+        const int t = r - b * v.rows_per_batch;
+        return v.off + (long long)b * v.batch_stride + (long long)t * v.ld;
+    }
+    return v.off + (long long)r * v.ld;
+}
