@@ -21,9 +21,9 @@ class RowView(C.Structure):
 class GemmParams(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
                 ("resid", C.c_void_p), ("aux_out", C.c_void_p), ("aux_in", C.c_void_p),
-                ("a", RowView), ("b", RowView), ("c", RowView),
+                ("a", RowView), ("b", RowView), ("c", RowView), ("e", RowView),
                 ("batch_a", C.c_longlong), ("batch_b", C.c_longlong), ("batch_c", C.c_longlong),
-                ("batch_bias", C.c_longlong),
+                ("batch_bias", C.c_longlong), ("batch_e", C.c_longlong),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_rc", C.c_int), ("b_rc", C.c_int),
                 ("act", C.c_int), ("out_f32", C.c_int), ("atomic", C.c_int), ("nbatch", C.c_int),
                 ("split_k", C.c_int), ("tr_mode", C.c_int), ("alpha", C.c_float)]
@@ -73,3 +73,26 @@ class AttnParams(C.Structure):
                 ("dv_bs", C.c_longlong), ("dv_ld", C.c_longlong), ("do_bs", C.c_longlong), ("do_ld", C.c_longlong),
                 ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("D", C.c_int),
                 ("causal", C.c_int), ("scale", C.c_float)]
+
+
+class Conv0Params(C.Structure):
+    _fields_ = [("wave", C.c_void_p), ("w", C.c_void_p), ("cbias", C.c_void_p), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("stats", C.c_void_p), ("y", C.c_void_p), ("dy", C.c_void_p),
+                ("bstats", C.c_void_p), ("dw", C.c_void_p), ("dcbias", C.c_void_p), ("dgamma", C.c_void_p),
+                ("dbeta", C.c_void_p),
+                ("B", C.c_int), ("N", C.c_int), ("C", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("T0", C.c_int),
+                ("group", C.c_int), ("eps", C.c_float)]
+
+
+class CEParams(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("labels", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p),
+                ("dlogits", C.c_void_p), ("lse", C.c_void_p), ("M", C.c_int), ("V", C.c_int),
+                ("ldl", C.c_longlong), ("ldd", C.c_longlong), ("gscale", C.c_float)]
+
+
+class OptParams(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("shadow", C.c_void_p),
+                ("gnorm_sq", C.c_void_p), ("n", C.c_longlong),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("bias_c1", C.c_float), ("bias_c2", C.c_float),
+                ("grad_scale", C.c_float), ("max_grad_norm", C.c_float), ("kind", C.c_int)]

@@ -33,31 +33,32 @@ struct SmxAttnParams {
 
 // ============================== fp32 simple kernels ==============================================
 #define SIMPLE_MAXD 128
-__global__ void attn_fwd_f32(SmxAttnParams p) {
+template <typename T>
+__global__ void attn_fwd_simple(SmxAttnParams p) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.B * p.H * p.Tq) return;
     const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
-    const float* Q = reinterpret_cast<const float*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
-    const float* K = reinterpret_cast<const float*>(p.K) + b * p.k_bs + h * p.D;
-    const float* V = reinterpret_cast<const float*>(p.V) + b * p.v_bs + h * p.D;
+    const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
+    const T* K = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * p.D;
+    const T* V = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * p.D;
     float o[SIMPLE_MAXD];
     for (int d = 0; d < p.D; ++d) o[d] = 0.f;
     float m = NEG_BIG, l = 0.f;
     const int kmax = p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk;
     for (int k = 0; k < kmax; ++k) {
         float s = 0.f;
-        for (int d = 0; d < p.D; ++d) s = fmaf(Q[d], K[k * p.k_ld + d], s);
+        for (int d = 0; d < p.D; ++d) s = fmaf(Cvt<T>::ld(Q + d), Cvt<T>::ld(K + k * p.k_ld + d), s);
         s *= p.scale;
         if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
         const float mn = fmaxf(m, s);
         const float a = expf(m - mn), e = expf(s - mn);
         l = l * a + e;
-        for (int d = 0; d < p.D; ++d) o[d] = o[d] * a + e * V[k * p.v_ld + d];
+        for (int d = 0; d < p.D; ++d) o[d] = o[d] * a + e * Cvt<T>::ld(V + k * p.v_ld + d);
         m = mn;
     }
-    float* O = reinterpret_cast<float*>(p.O) + b * p.o_bs + q * p.o_ld + h * p.D;
+    T* O = reinterpret_cast<T*>(p.O) + b * p.o_bs + q * p.o_ld + h * p.D;
     const float inv = 1.f / l;
-    for (int d = 0; d < p.D; ++d) O[d] = o[d] * inv;
+    for (int d = 0; d < p.D; ++d) Cvt<T>::st(O + d, o[d] * inv);
     p.lse[idx] = m + logf(l);
 }
 
@@ -79,14 +80,15 @@ __global__ void attn_delta_kernel(SmxAttnParams p) {
     p.delta[idx] = s;
 }
 
-__global__ void attn_bwd_dq_f32(SmxAttnParams p) {
+template <typename T>
+__global__ void attn_bwd_dq_simple(SmxAttnParams p) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.B * p.H * p.Tq) return;
     const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
-    const float* Q = reinterpret_cast<const float*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
-    const float* dO = reinterpret_cast<const float*>(p.dO) + b * p.do_bs + q * p.do_ld + h * p.D;
-    const float* K = reinterpret_cast<const float*>(p.K) + b * p.k_bs + h * p.D;
-    const float* V = reinterpret_cast<const float*>(p.V) + b * p.v_bs + h * p.D;
+    const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
+    const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + q * p.do_ld + h * p.D;
+    const T* K = reinterpret_cast<const T*>(p.K) + b * p.k_bs + h * p.D;
+    const T* V = reinterpret_cast<const T*>(p.V) + b * p.v_bs + h * p.D;
     const float lse = p.lse[idx], delta = p.delta[idx];
     float dq[SIMPLE_MAXD];
     for (int d = 0; d < p.D; ++d) dq[d] = 0.f;
@@ -94,35 +96,36 @@ __global__ void attn_bwd_dq_f32(SmxAttnParams p) {
     for (int k = 0; k < kmax; ++k) {
         float s = 0.f, dp = 0.f;
         for (int d = 0; d < p.D; ++d) {
-            s = fmaf(Q[d], K[k * p.k_ld + d], s);
-            dp = fmaf(dO[d], V[k * p.v_ld + d], dp);
+            s = fmaf(Cvt<T>::ld(Q + d), Cvt<T>::ld(K + k * p.k_ld + d), s);
+            dp = fmaf(Cvt<T>::ld(dO + d), Cvt<T>::ld(V + k * p.v_ld + d), dp);
         }
         s *= p.scale;
         if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
         const float ds = expf(s - lse) * (dp - delta);
         if (p.dbias) atomicAdd(p.dbias + ((long long)h * p.Tq + q) * p.Tk + k, ds);
-        for (int d = 0; d < p.D; ++d) dq[d] = fmaf(ds * p.scale, K[k * p.k_ld + d], dq[d]);
+        for (int d = 0; d < p.D; ++d) dq[d] = fmaf(ds * p.scale, Cvt<T>::ld(K + k * p.k_ld + d), dq[d]);
     }
-    float* dQ = reinterpret_cast<float*>(p.dQ) + b * p.dq_bs + q * p.dq_ld + h * p.D;
-    for (int d = 0; d < p.D; ++d) dQ[d] = dq[d];
+    T* dQ = reinterpret_cast<T*>(p.dQ) + b * p.dq_bs + q * p.dq_ld + h * p.D;
+    for (int d = 0; d < p.D; ++d) Cvt<T>::st(dQ + d, dq[d]);
 }
 
-__global__ void attn_bwd_dkv_f32(SmxAttnParams p) {
+template <typename T>
+__global__ void attn_bwd_dkv_simple(SmxAttnParams p) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.B * p.H * p.Tk) return;
     const int k = idx % p.Tk, h = (idx / p.Tk) % p.H, b = idx / (p.Tk * p.H);
-    const float* Kp = reinterpret_cast<const float*>(p.K) + b * p.k_bs + k * p.k_ld + h * p.D;
-    const float* Vp = reinterpret_cast<const float*>(p.V) + b * p.v_bs + k * p.v_ld + h * p.D;
-    const float* Q = reinterpret_cast<const float*>(p.Q) + b * p.q_bs + h * p.D;
-    const float* dO = reinterpret_cast<const float*>(p.dO) + b * p.do_bs + h * p.D;
+    const T* Kp = reinterpret_cast<const T*>(p.K) + b * p.k_bs + k * p.k_ld + h * p.D;
+    const T* Vp = reinterpret_cast<const T*>(p.V) + b * p.v_bs + k * p.v_ld + h * p.D;
+    const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + h * p.D;
+    const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + h * p.D;
     float dk[SIMPLE_MAXD], dv[SIMPLE_MAXD];
     for (int d = 0; d < p.D; ++d) dk[d] = dv[d] = 0.f;
     const int q0 = p.causal ? max(0, k - (p.Tk - p.Tq)) : 0;
     for (int q = q0; q < p.Tq; ++q) {
         float s = 0.f, dp = 0.f;
         for (int d = 0; d < p.D; ++d) {
-            s = fmaf(Q[q * p.q_ld + d], Kp[d], s);
-            dp = fmaf(dO[q * p.do_ld + d], Vp[d], dp);
+            s = fmaf(Cvt<T>::ld(Q + q * p.q_ld + d), Cvt<T>::ld(Kp + d), s);
+            dp = fmaf(Cvt<T>::ld(dO + q * p.do_ld + d), Cvt<T>::ld(Vp + d), dp);
         }
         s *= p.scale;
         if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
@@ -130,13 +133,13 @@ __global__ void attn_bwd_dkv_f32(SmxAttnParams p) {
         const float pr = expf(s - p.lse[li]);
         const float ds = pr * (dp - p.delta[li]) * p.scale;
         for (int d = 0; d < p.D; ++d) {
-            dv[d] = fmaf(pr, dO[q * p.do_ld + d], dv[d]);
-            dk[d] = fmaf(ds, Q[q * p.q_ld + d], dk[d]);
+            dv[d] = fmaf(pr, Cvt<T>::ld(dO + q * p.do_ld + d), dv[d]);
+            dk[d] = fmaf(ds, Cvt<T>::ld(Q + q * p.q_ld + d), dk[d]);
         }
     }
-    float* dK = reinterpret_cast<float*>(p.dK) + b * p.dk_bs + k * p.dk_ld + h * p.D;
-    float* dV = reinterpret_cast<float*>(p.dV) + b * p.dv_bs + k * p.dv_ld + h * p.D;
-    for (int d = 0; d < p.D; ++d) { dK[d] = dk[d]; dV[d] = dv[d]; }
+    T* dK = reinterpret_cast<T*>(p.dK) + b * p.dk_bs + k * p.dk_ld + h * p.D;
+    T* dV = reinterpret_cast<T*>(p.dV) + b * p.dv_bs + k * p.dv_ld + h * p.D;
+    for (int d = 0; d < p.D; ++d) { Cvt<T>::st(dK + d, dk[d]); Cvt<T>::st(dV + d, dv[d]); }
 }
 
 // ============================== bf16 MFMA kernels (D = 64) =======================================
@@ -442,8 +445,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(SmxAttnParams p) {
 
 static int attn_check(const SmxAttnParams& p, int dtype) {
     if (p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return SMX_EINVAL;
-    if (dtype == SMX_BF16 && p.D != 64) return SMX_EINVAL;
-    if (dtype == SMX_F32 && (p.D > SIMPLE_MAXD || (p.D & 7))) return SMX_EINVAL;
+    if ((dtype == SMX_F32 || p.D != 64) && (p.D > SIMPLE_MAXD || (p.D & 7))) return SMX_EINVAL;
     if (p.causal && p.Tk < p.Tq) return SMX_EINVAL;
     return SMX_OK;
 }
@@ -454,7 +456,10 @@ extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t
     if (rc) return rc;
     if (dtype == SMX_F32) {
         const int n = p.B * p.H * p.Tq;
-        hipLaunchKernelGGL(attn_fwd_f32, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(attn_fwd_simple<float>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+    } else if (dtype == SMX_BF16 && p.D != 64) {   // head widths off the hot path (tiny test configs)
+        const int n = p.B * p.H * p.Tq;
+        hipLaunchKernelGGL(attn_fwd_simple<bf16_t>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
     } else if (dtype == SMX_BF16) {
         hipLaunchKernelGGL(attn_fwd_bf16, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
     } else return SMX_EINVAL;
@@ -469,9 +474,14 @@ extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t
     const int n = p.B * p.H * p.Tq;
     if (dtype == SMX_F32) {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(attn_bwd_dq_f32, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dq_simple<float>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
         const int nk = p.B * p.H * p.Tk;
-        hipLaunchKernelGGL(attn_bwd_dkv_f32, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_simple<float>, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
+    } else if (dtype == SMX_BF16 && p.D != 64) {
+        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dq_simple<bf16_t>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+        const int nk = p.B * p.H * p.Tk;
+        hipLaunchKernelGGL(attn_bwd_dkv_simple<bf16_t>, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
     } else if (dtype == SMX_BF16) {
         if (p.dbias) return SMX_EINVAL;
         hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
@@ -480,3 +490,6 @@ extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t
     } else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
+
+// ABI self-description (checked by the ctypes binding against its struct mirrors)
+extern "C" int smx_sizeof_SmxAttnParams(void) { return (int)sizeof(SmxAttnParams); }

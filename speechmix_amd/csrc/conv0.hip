@@ -308,3 +308,6 @@ extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t st
     }
     SMX_CHECK_LAUNCH();
 }
+
+// ABI self-description (checked by the ctypes binding against its struct mirrors)
+extern "C" int smx_sizeof_SmxConv0Params(void) { return (int)sizeof(SmxConv0Params); }

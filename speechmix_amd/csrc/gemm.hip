@@ -26,7 +26,8 @@ struct SmxGemmParams {
     void* aux_out;          // pre-activation copy (same view as C) or null
     const void* aux_in;     // pre-activation of the consumer: C *= act'(aux_in) (same view as C) or null
     SmxRowView a, b, c;
-    long long batch_a, batch_b, batch_c, batch_bias;  // element strides between grid.z batches
+    SmxRowView e;           // view of the epilogue side tensors (resid / aux_out / aux_in); usually == c
+    long long batch_a, batch_b, batch_c, batch_bias, batch_e;  // element strides between grid.z batches
     int M, N, K;
     int a_rc, b_rc;
     int act;                // SMX_ACT_* applied after bias (fwd) or used for aux_in derivative
@@ -133,21 +134,22 @@ __device__ __forceinline__ bf16x8_t load_frag(const char* tile, int r16, int kk,
 }
 
 template <typename TOUT>
-__device__ __forceinline__ void epilogue4(const SmxGemmParams& p, long long zc, long long zbias, int m, int n0,
-                                          float v[4]) {
+__device__ __forceinline__ void epilogue4(const SmxGemmParams& p, long long zc, long long zbias, long long ze, int m,
+                                          int n0, float v[4]) {
     // lane owns C[m, n0..n0+3]
     if (m >= p.M || n0 >= p.N) return;
     const long long base = zc + view_off(p.c, m) + n0;
+    const long long sb = (p.resid || p.aux_out || p.aux_in) ? ze + view_off(p.e, m) + n0 : 0;
     const int nv = min(4, p.N - n0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j < nv) {
             float x = v[j] * p.alpha;
             if (p.bias) x += p.bias[zbias + n0 + j];
-            if (p.aux_out) reinterpret_cast<bf16_t*>(p.aux_out)[base + j] = f2bf(x);
+            if (p.aux_out) reinterpret_cast<bf16_t*>(p.aux_out)[sb + j] = f2bf(x);
             if (!p.aux_in) x = act_fwd(x, p.act);
-            else x *= act_grad(bf2f(reinterpret_cast<const bf16_t*>(p.aux_in)[base + j]), p.act);
-            if (p.resid) x += bf2f(reinterpret_cast<const bf16_t*>(p.resid)[base + j]);
+            else x *= act_grad(bf2f(reinterpret_cast<const bf16_t*>(p.aux_in)[sb + j]), p.act);
+            if (p.resid) x += bf2f(reinterpret_cast<const bf16_t*>(p.resid)[sb + j]);
             v[j] = x;
         }
     }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
     const int zb = z / p.split_k, zs = z - zb * p.split_k;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
-    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias;
+    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
 
     // K range of this split (multiple of BK)
     const int ksteps_total = (p.K + BK - 1) / BK;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue4<bf16_t>(p, zc, zbias, m0 + wm * 64 + i * 16 + i16, n0 + wn * 64 + j * 16 + 4 * g, v);
+            epilogue4<bf16_t>(p, zc, zbias, ze, m0 + wm * 64 + i * 16 + i16, n0 + wn * 64 + j * 16 + 4 * g, v);
         }
 }
 
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
     const int zb = z / p.split_k, zs = z - zb * p.split_k;
     const float* A = reinterpret_cast<const float*>(p.A) + (long long)zb * p.batch_a;
     const float* B = reinterpret_cast<const float*>(p.B) + (long long)zb * p.batch_b;
-    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias;
+    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
     const int ksteps_total = (p.K + 15) / 16;
     const int per = (ksteps_total + p.split_k - 1) / p.split_k;
     const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
@@ -329,16 +331,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
         const int m = m0 + ty * 4 + i;
         if (m >= p.M) continue;
         const long long rowb = zc + view_off(p.c, m);
+        const long long rowe = ze + view_off(p.e, m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + tx * 4 + j;
             if (n >= p.N) continue;
             float x = acc[i][j] * p.alpha;
             if (p.bias) x += p.bias[zbias + n];
-            if (p.aux_out) reinterpret_cast<float*>(p.aux_out)[rowb + n] = x;
+            if (p.aux_out) reinterpret_cast<float*>(p.aux_out)[rowe + n] = x;
             if (!p.aux_in) x = act_fwd(x, p.act);
-            else x *= act_grad(reinterpret_cast<const float*>(p.aux_in)[rowb + n], p.act);
-            if (p.resid) x += reinterpret_cast<const float*>(p.resid)[rowb + n];
+            else x *= act_grad(reinterpret_cast<const float*>(p.aux_in)[rowe + n], p.act);
+            if (p.resid) x += reinterpret_cast<const float*>(p.resid)[rowe + n];
             float* c = reinterpret_cast<float*>(p.C) + rowb + n;
             if (p.atomic) atomicAdd(c, x); else *c = x;
         }
@@ -371,3 +374,6 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
         hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), lds, stream, p);
     SMX_CHECK_LAUNCH();
 }
+
+// ABI self-description (checked by the ctypes binding against its struct mirrors)
+extern "C" int smx_sizeof_SmxGemmParams(void) { return (int)sizeof(SmxGemmParams); }

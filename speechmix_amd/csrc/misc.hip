@@ -1,0 +1,336 @@
+// Small HBM-bound kernels around the GEMMs: dtype casts, conv-weight re-layouts, token embedding
+// gather / scatter, bias-gradient column sums, fused cross-entropy (+argmax, +dlogits), SpecAugment row
+// masking, element-wise adds.  All fp32 statistics; 16-B accesses where layouts allow.
+#include "smx_common.h"
+
+// ---------------------------------------------------------------- cast fp32 -> T
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long stride = (long long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += stride) {
+        float v[8];
+        load8(src + i, v);
+        store8(dst + i, v);
+    }
+    if (i < n && i + 8 > n)
+        for (long long j = i; j < n; ++j) Cvt<T>::st(dst + j, src[j]);
+}
+extern "C" int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream) {
+    if (n <= 0) return SMX_OK;
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, stream, src, (float*)dst, n);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// T -> fp32 (outputs handed back to PyTorch callers: raw logits, hidden states)
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = Cvt<T>::ld(src + i);
+}
+extern "C" int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream) {
+    if (n <= 0) return SMX_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, dst, n);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)src, dst, n);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- conv weight re-layout
+// nn.Conv1d weight [Co, Ci, k] fp32  ->  tap-major GEMM operand [Co, k*Ci] (dtype T): the K index of the
+// GEMM then walks a contiguous channels-last input window (TF:...wav2vec2.py:254-273 conv as GEMM).
+template <typename T>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int k) {
+    const long long n = (long long)Co * Ci * k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci, t = (i / Ci) % k, co = i / ((long long)Ci * k);
+        Cvt<T>::st(out + i, w[((long long)co * Ci + ci) * k + t]);
+    }
+}
+extern "C" int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k, int dtype, hipStream_t stream) {
+    const long long n = (long long)Co * Ci * k;
+    int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(pack_conv_w_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w, (bf16_t*)out, Co, Ci, k);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(pack_conv_w_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, (float*)out, Co, Ci, k);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+// dW (tap-major fp32 [Co, k*Ci]) accumulated into the parameter-layout gradient [Co, Ci, k]
+__global__ void unpack_conv_dw_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int k) {
+    const long long n = (long long)Co * Ci * k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci, t = (i / Ci) % k, co = i / ((long long)Ci * k);
+        dw[((long long)co * Ci + ci) * k + t] += dwp[i];
+    }
+}
+extern "C" int smx_unpack_conv_dw(const float* dwp, float* dw, int Co, int Ci, int k, hipStream_t stream) {
+    const long long n = (long long)Co * Ci * k;
+    int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(unpack_conv_dw_kernel, dim3(blocks), dim3(256), 0, stream, dwp, dw, Co, Ci, k);
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- token embedding
+// out[r,:] = table[ids[r],:] * scale   (TF:models/bart/modeling_bart.py:101-113)
+template <typename T>
+__global__ void embed_fwd_kernel(const long long* __restrict__ ids, const T* __restrict__ table, T* __restrict__ out,
+                                 int M, int D, float scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const T* src = table + ids[row] * (long long)D;
+    T* dst = out + (long long)row * D;
+    for (int c = lane * 8; c < D; c += 512) {
+        float v[8];
+        load8(src + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= scale;
+        store8(dst + c, v);
+    }
+}
+extern "C" int smx_embed_fwd(const long long* ids, const void* table, void* out, int M, int D, float scale, int dtype,
+                             hipStream_t stream) {
+    if (M <= 0 || (D & 7)) return SMX_EINVAL;
+    dim3 grid((M + 3) / 4);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, (const bf16_t*)table, (bf16_t*)out, M, D, scale);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, stream, ids, (const float*)table, (float*)out, M, D, scale);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+template <typename T>
+__global__ void embed_bwd_kernel(const long long* __restrict__ ids, const T* __restrict__ dy, float* __restrict__ dtable,
+                                 int M, int D, float scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float* dst = dtable + ids[row] * (long long)D;
+    const T* src = dy + (long long)row * D;
+    for (int c = lane * 8; c < D; c += 512) {
+        float v[8];
+        load8(src + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dst + c + e, v[e] * scale);
+    }
+}
+extern "C" int smx_embed_bwd(const long long* ids, const void* dy, float* dtable, int M, int D, float scale, int dtype,
+                             hipStream_t stream) {
+    if (M <= 0 || (D & 7)) return SMX_EINVAL;
+    dim3 grid((M + 3) / 4);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, (const bf16_t*)dy, dtable, M, D, scale);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, stream, ids, (const float*)dy, dtable, M, D, scale);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients)
+// out[n] += alpha * sum_m x[m*ld + n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                     long long ld, float alpha) {
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < N) {
+        for (int m = blockIdx.y * 4 + w; m < M; m += gridDim.y * 4) {
+            float v[8];
+            if (c + 8 <= N) load8(x + (long long)m * ld + c, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = c + e < N ? Cvt<T>::ld(x + (long long)m * ld + c + e) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[w][lane][e] = acc[e];
+    __syncthreads();
+    if (w == 0 && c < N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (c + e < N) atomicAdd(out + c + e, alpha * (red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e]));
+    }
+}
+extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || (ld & 7)) return SMX_EINVAL;
+    int gy = (M + 63) / 64;
+    if (gy > 64) gy = 64;
+    dim3 grid((N + 511) / 512, gy);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, M, N, ld, alpha);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, M, N, ld, alpha);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- cross entropy over the vocabulary
+// CrossEntropyLoss(ignore_index=-100, mean)  (TF:models/bart/modeling_bart.py:942-946) fused with
+// argmax (ref:speechmix/model.py:174) and the logits gradient.  One block per token row.
+struct SmxCEParams {
+    const float* logits;       // [M, ldl] fp32
+    const long long* labels;   // [M] or null (no loss: argmax only)
+    float* loss;               // scalar, atomically accumulated: sum_rows loss_row / n_valid
+    long long* argmax;         // [M] or null
+    void* dlogits;             // [M, ldd] dtype T (pad columns zeroed) or null
+    float* lse;                // [M] optional: log-sum-exp per row
+    int M, V;
+    long long ldl, ldd;
+    float gscale;              // multiplies dlogits (upstream gradient)
+};
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
+    __shared__ float sh[16];
+    __shared__ float shv[4];
+    __shared__ int shi[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* z = p.logits + (long long)row * p.ldl;
+    float nvalid = 0.f;
+    if (p.labels) {
+        for (int i = tid; i < p.M; i += 256) nvalid += p.labels[i] != -100 ? 1.f : 0.f;
+        nvalid = block_sum(nvalid, sh);
+    }
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int j = tid; j < p.V; j += 256) {
+        const float v = z[j];
+        if (v > mx) { mx = v; mi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { shv[tid >> 6] = mx; shi[tid >> 6] = mi; }
+    __syncthreads();
+    mx = shv[0]; mi = shi[0];
+    for (int w = 1; w < 4; ++w)
+        if (shv[w] > mx || (shv[w] == mx && shi[w] < mi)) { mx = shv[w]; mi = shi[w]; }
+    if (p.argmax && tid == 0) p.argmax[row] = mi;
+    if (!p.labels && !p.lse) return;
+    float se = 0.f;
+    for (int j = tid; j < p.V; j += 256) se += __expf(z[j] - mx);
+    se = block_sum(se, sh);
+    const float lse = mx + __logf(se);
+    if (p.lse && tid == 0) p.lse[row] = lse;
+    if (!p.labels) return;
+    const long long lab = p.labels[row];
+    const bool valid = lab != -100;
+    if (valid && tid == 0) atomicAdd(p.loss, (lse - z[lab]) / nvalid);
+    if (p.dlogits) {
+        T* d = reinterpret_cast<T*>(p.dlogits) + (long long)row * p.ldd;
+        const float coef = valid ? p.gscale / nvalid : 0.f;
+        for (int j = tid; j < p.ldd; j += 256) {
+            float g = 0.f;
+            if (j < p.V && valid) g = (__expf(z[j] - lse) - (j == lab ? 1.f : 0.f)) * coef;
+            Cvt<T>::st(d + j, g);
+        }
+    }
+}
+extern "C" int smx_cross_entropy(const SmxCEParams* pp, int dtype, hipStream_t stream) {
+    SmxCEParams p = *pp;
+    if (p.M <= 0 || p.V <= 0 || p.ldl < p.V) return SMX_EINVAL;
+    if (p.dlogits && p.ldd < p.V) return SMX_EINVAL;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(ce_kernel<bf16_t>, dim3(p.M), dim3(256), 0, stream, p);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(ce_kernel<float>, dim3(p.M), dim3(256), 0, stream, p);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- element-wise: out = a + b
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long stride = (long long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += stride) {
+        float x[8], y[8];
+        load8(a + i, x);
+        load8(b + i, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += y[e];
+        store8(out + i, x);
+    }
+}
+extern "C" int smx_add(const void* a, const void* b, void* out, long long n, int dtype, hipStream_t stream) {
+    if (n <= 0 || (n & 7)) return SMX_EINVAL;
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, n);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- SpecAugment time masking
+// rows listed in `rows` are overwritten with the learned masked_spec_embed
+// (TF:models/wav2vec2/modeling_wav2vec2.py:1272-1316; indices are drawn on the host).
+template <typename T>
+__global__ void mask_rows_kernel(T* __restrict__ x, const int* __restrict__ rows, int nrows, const float* __restrict__ emb, int D) {
+    const int r = blockIdx.x;
+    if (r >= nrows) return;
+    T* dst = x + (long long)rows[r] * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) Cvt<T>::st(dst + c, emb[c]);
+}
+extern "C" int smx_mask_rows(void* x, const int* rows, int nrows, const float* emb, int D, int dtype, hipStream_t stream) {
+    if (nrows <= 0) return SMX_OK;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, dim3(nrows), dim3(256), 0, stream, (bf16_t*)x, rows, nrows, emb, D);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(mask_rows_kernel<float>, dim3(nrows), dim3(256), 0, stream, (float*)x, rows, nrows, emb, D);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+// backward: d_emb += sum over masked rows of dx; dx rows zeroed
+template <typename T>
+__global__ void mask_rows_bwd_kernel(T* __restrict__ dx, const int* __restrict__ rows, int nrows, float* __restrict__ demb, int D) {
+    const int r = blockIdx.x;
+    if (r >= nrows) return;
+    T* src = dx + (long long)rows[r] * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        if (demb) atomicAdd(demb + c, Cvt<T>::ld(src + c));
+        Cvt<T>::st(src + c, 0.f);
+    }
+}
+extern "C" int smx_mask_rows_bwd(void* dx, const int* rows, int nrows, float* demb, int D, int dtype, hipStream_t stream) {
+    if (nrows <= 0) return SMX_OK;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(mask_rows_bwd_kernel<bf16_t>, dim3(nrows), dim3(256), 0, stream, (bf16_t*)dx, rows, nrows, demb, D);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(mask_rows_bwd_kernel<float>, dim3(nrows), dim3(256), 0, stream, (float*)dx, rows, nrows, demb, D);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ABI self-description (checked by the ctypes binding against its struct mirrors)
+extern "C" int smx_sizeof_SmxCEParams(void) { return (int)sizeof(SmxCEParams); }
+
+// ---------------------------------------------------------------- dx = dy * act'(pre), rows written through a view
+// (lets the result land inside a zero-padded per-clip buffer that the conv dgrad GEMMs window over)
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ dx, int M, int N,
+                               SmxRowView ov, int act) {
+    const int cv = N / 8;
+    const long long n = (long long)M * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int m = i / cv, c = (i % cv) * 8;
+        float d[8], x[8];
+        load8(dy + (long long)m * N + c, d);
+        load8(pre + (long long)m * N + c, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] *= act_grad(x[e], act);
+        store8(dx + view_off(ov, m) + c, d);
+    }
+}
+extern "C" int smx_act_bwd(const void* dy, const void* pre, void* dx, int M, int N, const SmxRowView* ov, int act, int dtype,
+                           hipStream_t stream) {
+    if (M <= 0 || (N & 7)) return SMX_EINVAL;
+    const long long n = (long long)M * (N / 8);
+    int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)dx, M, N, *ov, act);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, (const float*)pre, (float*)dx, M, N, *ov, act);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}

@@ -223,3 +223,7 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
+
+// ABI self-description (checked by the ctypes binding against its struct mirrors)
+extern "C" int smx_sizeof_SmxNormParams(void) { return (int)sizeof(SmxNormParams); }
+extern "C" int smx_sizeof_SmxNormBwdParams(void) { return (int)sizeof(SmxNormBwdParams); }

@@ -1,0 +1,835 @@
+"""Hand-scheduled forward + backward of the SpeechMix training step on HIP kernels.
+
+This is the MI355X-native replacement for what PyTorch autograd + HF modules execute under
+`SpeechMixEED.forward` / `loss.backward()` in the reference (ref:speechmix/model.py:139-177):
+an explicit stage list (CNN feature extractor -> projection -> positional conv -> encoder layers -> length
+adapters -> enc_to_dec_proj -> LM text encoder -> LM decoder -> LM head + CE), each stage with a forward that
+saves exactly what its hand-written backward needs.  All arithmetic is in libspeechmix_hip.so; torch is used
+for device buffers only.  Data layout: activations are token-major / channels-last `[B*T, C]` in the compute
+dtype (bf16, or fp32 on the parity path); every Conv1d is a GEMM over an overlapping row view of that layout
+(no im2col, no col2im); parameters are read from the FlatStore's compute copy, gradients are accumulated in
+fp32 straight into the FlatStore's flat gradient buffer (the thing RCCL all-reduces).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .configs import LMConfig, SpeechEncoderConfig
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, view
+from .params import FlatStore
+
+_ACT = {"gelu": ACT_GELU, "relu": ACT_RELU}
+
+
+def _act_id(name):
+    if name not in _ACT:
+        raise ValueError(f"activation {name!r} is not supported by the HIP kernels (gelu / relu)")
+    return _ACT[name]
+
+
+class Engine:
+    def __init__(self, store: FlatStore, enc_cfg: SpeechEncoderConfig, lm_cfg: LMConfig, dtype: int,
+                 num_speech_layers: int, down_scale: int, enc_prefix="encoder_model.", lm_prefix="decoder_model."):
+        self.st = store
+        self.ec, self.lc = enc_cfg, lm_cfg
+        self.dt = dtype
+        self.tdt = ops.torch_dtype(dtype)
+        self.dev = store.device
+        self.L = num_speech_layers
+        self.downloop = int(math.log(down_scale, 2)) if down_scale > 1 else 0
+        self.ep, self.lp = enc_prefix, lm_prefix
+        self._persist: Dict[str, torch.Tensor] = {}
+        self.saved = None
+        self.rng = np.random.default_rng(0)
+
+    # ------------------------------------------------------------------ buffers / parameter access
+    def new(self, *shape, dt=None):
+        return torch.empty(shape, dtype=dt or self.tdt, device=self.dev)
+
+    def zeros(self, *shape, dt=None):
+        return torch.zeros(shape, dtype=dt or self.tdt, device=self.dev)
+
+    def persist_zeros(self, key, *shape, dt=None):
+        """Zero-initialised buffer that lives across steps (kernels only ever write its interior rows)."""
+        t = self._persist.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != (dt or self.tdt):
+            t = self.zeros(*shape, dt=dt)
+            self._persist[key] = t
+        return t
+
+    def W(self, n): return self.st.w(n)
+    def P(self, n): return self.st.p32(n)
+    def G(self, n): return self.st.g(n)
+    def has(self, n): return n in self.st.offsets
+    def tr(self, *names): return any(self.st.requires_grad(n) for n in names)
+
+    def _split(self, Mo, No, Kred):
+        tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
+        ksteps = (Kred + 63) // 64
+        return int(max(1, min(512 // max(tiles, 1), ksteps // 8, 32)))
+
+    # ------------------------------------------------------------------ linear building blocks
+    def lin(self, x, w, b, M, N, K, y=None, act=ACT_NONE, resid=None, aux_out=None, av=None, cv=None, ev=None,
+            alpha=1.0, out_f32=False, **kw):
+        if y is None:
+            y = self.new(M, N, dt=torch.float32 if out_f32 else None)
+        ops.gemm(x, w, y, M, N, K, self.dt, av=av, cv=cv, ev=ev, bias=b, resid=resid, aux_out=aux_out, act=act,
+                 alpha=alpha, out_f32=out_f32, **kw)
+        return y
+
+    def dgrad(self, dy, w, dx, M, N, K, resid=None, aux_in=None, act=ACT_NONE, av=None, bv=None, cv=None, ev=None,
+              alpha=1.0, **kw):
+        """dx[M,K] = dy[M,N] @ w[N,K]   (w read rows-contiguous: no transposed weight copy)."""
+        ops.gemm(dy, w, dx, M, K, N, self.dt, b_rc=True, av=av, bv=bv if bv is not None else view(K), cv=cv, ev=ev,
+                 resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
+        return dx
+
+    def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, **kw):
+        """gw[N,K] += dy[M,N]^T @ x[M,K]  (fp32 atomics, split over M);  gb[N] += colsum(dy)."""
+        ops.gemm(dy, x, gw, N, K, M, self.dt, a_rc=True, b_rc=True, av=dyv if dyv is not None else view(N),
+                 bv=xv if xv is not None else view(K), out_f32=True, atomic=True, split_k=self._split(N, K, M),
+                 alpha=alpha, **kw)
+        if gb is not None:
+            ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha)
+
+    def ln_fwd(self, x, wname, bname, M, D, eps, rms=False, act=ACT_NONE, pos=None, pos_period=0, pos_offset=0,
+               want_sum=False):
+        y = self.new(M, D)
+        mean = None if rms else self.new(M, dt=torch.float32)
+        rstd = self.new(M, dt=torch.float32)
+        xs = self.new(M, D) if want_sum else None
+        ops.norm_fwd(x, y, self.P(wname), self.P(bname) if bname else None, mean, rstd, M, D, self.dt, eps=eps, rms=rms,
+                     act=act, pos=pos, pos_period=pos_period, pos_offset=pos_offset, xsum_out=xs)
+        return y, (xs if want_sum else x, mean, rstd)
+
+    def ln_bwd(self, dy, saved, wname, bname, M, D, rms=False, act=ACT_NONE, dres=None, dpos=None, pos_period=0,
+               pos_offset=0, dx=None):
+        x, mean, rstd = saved
+        dx = dx if dx is not None else self.new(M, D)
+        train = self.tr(wname)
+        ops.norm_bwd(dy, x, dx, self.P(wname), self.P(bname) if bname else None, mean, rstd,
+                     self.G(wname) if train else None, self.G(bname) if (bname and train) else None, M, D, self.dt,
+                     rms=rms, act=act, dres=dres, dpos=dpos, pos_period=pos_period, pos_offset=pos_offset)
+        return dx
+
+    # ------------------------------------------------------------------ attention block (self or cross)
+    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None):
+        """names: dict(q,k,v,o -> (weight, bias|None)).  Returns (o [B*Tq, d], saved)."""
+        Mq, Mk = B * Tq, B * Tk
+        hd = d // H
+        self_attn = kvsrc is None
+        qn, kn, vn = names["q"], names["k"], names["v"]
+        if self_attn:
+            wqkv = self.st.cat([qn[0], kn[0], vn[0]])
+            bqkv = self.st.cat([qn[1], kn[1], vn[1]], "p32") if qn[1] else None
+            qkv = self.lin(x, wqkv, bqkv, Mq, 3 * d, d)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias)
+            desc.set("Q", qkv, 0, Tq * 3 * d, 3 * d)
+            desc.set("K", qkv, d, Tk * 3 * d, 3 * d)
+            desc.set("V", qkv, 2 * d, Tk * 3 * d, 3 * d)
+            kv = None
+        else:
+            qkv = self.lin(x, self.W(qn[0]), self.P(qn[1]) if qn[1] else None, Mq, d, d)
+            wkv = self.st.cat([kn[0], vn[0]])
+            bkv = self.st.cat([kn[1], vn[1]], "p32") if kn[1] else None
+            kv = self.lin(kvsrc, wkv, bkv, Mk, 2 * d, d)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias)
+            desc.set("Q", qkv, 0, Tq * d, d)
+            desc.set("K", kv, 0, Tk * 2 * d, 2 * d)
+            desc.set("V", kv, d, Tk * 2 * d, 2 * d)
+        o = self.new(Mq, d)
+        lse = self.new(B * H * Tq, dt=torch.float32)
+        desc.set("O", o, 0, Tq * d, d)
+        ops.attention_fwd(desc, lse, self.dt)
+        return o, dict(x=x, kvsrc=kvsrc, qkv=qkv, kv=kv, o=o, lse=lse, desc=desc, dims=(B, Tq, Tk, d, H))
+
+    def attn_bwd(self, do, sv, names, dx_resid=None, dkv_accum=None, dx=None):
+        """do: grad wrt attention output o (before out_proj).  Returns dx (grad wrt x, + dx_resid).
+        Cross attention: grad wrt kvsrc is accumulated into dkv_accum [B*Tk, d] (must be pre-initialised)."""
+        B, Tq, Tk, d, H = sv["dims"]
+        Mq, Mk = B * Tq, B * Tk
+        desc = sv["desc"]
+        qn, kn, vn = names["q"], names["k"], names["v"]
+        delta = self.new(B * H * Tq, dt=torch.float32)
+        desc.set("dO", do, 0, Tq * d, d)
+        if sv["kvsrc"] is None:
+            dqkv = self.new(Mq, 3 * d)
+            desc.set("dQ", dqkv, 0, Tq * 3 * d, 3 * d)
+            desc.set("dK", dqkv, d, Tk * 3 * d, 3 * d)
+            desc.set("dV", dqkv, 2 * d, Tk * 3 * d, 3 * d)
+            ops.attention_bwd(desc, sv["lse"], delta, self.dt)
+            wn = [qn[0], kn[0], vn[0]]
+            if self.tr(*wn):
+                self.wgrad(dqkv, sv["x"], self.st.cat(wn, "g"), Mq, 3 * d, d,
+                           gb=self.st.cat([qn[1], kn[1], vn[1]], "g") if qn[1] else None)
+            dx = dx if dx is not None else self.new(Mq, d)
+            self.dgrad(dqkv, self.st.cat(wn), dx, Mq, 3 * d, d, resid=dx_resid)
+            return dx
+        dq = self.new(Mq, d)
+        dkv = self.new(Mk, 2 * d)
+        desc.set("dQ", dq, 0, Tq * d, d)
+        desc.set("dK", dkv, 0, Tk * 2 * d, 2 * d)
+        desc.set("dV", dkv, d, Tk * 2 * d, 2 * d)
+        ops.attention_bwd(desc, sv["lse"], delta, self.dt)
+        if self.tr(qn[0]):
+            self.wgrad(dq, sv["x"], self.G(qn[0]), Mq, d, d, gb=self.G(qn[1]) if qn[1] else None)
+        if self.tr(kn[0], vn[0]):
+            self.wgrad(dkv, sv["kvsrc"], self.st.cat([kn[0], vn[0]], "g"), Mk, 2 * d, d,
+                       gb=self.st.cat([kn[1], vn[1]], "g") if kn[1] else None)
+        dx = dx if dx is not None else self.new(Mq, d)
+        self.dgrad(dq, self.W(qn[0]), dx, Mq, d, d, resid=dx_resid)
+        if dkv_accum is not None:
+            first = dkv_accum[1]
+            self.dgrad(dkv, self.st.cat([kn[0], vn[0]]), dkv_accum[0], Mk, 2 * d, d, resid=None if first else dkv_accum[0])
+        return dx
+
+    # ------------------------------------------------------------------ transformer layers
+    def _ffn_fwd(self, h, M, d, F, n1, n2, act, resid):
+        pre = self.new(M, F)
+        f = self.lin(h, self.W(n1[0]), self.P(n1[1]) if n1[1] else None, M, F, d, act=act, aux_out=pre)
+        y = self.lin(f, self.W(n2[0]), self.P(n2[1]) if n2[1] else None, M, d, F, resid=resid)
+        return y, (h, pre, f)
+
+    def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid):
+        """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid)."""
+        h, pre, f = sv
+        if self.tr(n2[0]):
+            self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=self.G(n2[1]) if n2[1] else None)
+        dpre = self.new(M, F)
+        self.dgrad(dy, self.W(n2[0]), dpre, M, d, F, aux_in=pre, act=act)
+        if self.tr(n1[0]):
+            self.wgrad(dpre, h, self.G(n1[0]), M, F, d, gb=self.G(n1[1]) if n1[1] else None)
+        dh = self.new(M, d)
+        self.dgrad(dpre, self.W(n1[0]), dh, M, F, d, resid=dx_resid)
+        return dh
+
+    def layer_fwd(self, x, B, T, d, H, F, nm, pre_ln, act, eps, causal=False, scale=None, enc=None, Tk=None, rms=False,
+                  bias=None, cross_bias=None):
+        """One transformer layer.  nm: dict with keys attn{q,k,v,o}, ln1, [xattn, lnx], fc1, fc2, ln2."""
+        M = B * T
+        scale = scale if scale is not None else (d // H) ** -0.5
+        sv = {}
+        if not pre_ln:
+            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias)
+            s1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x)
+            h, sv["ln1"] = self.ln_fwd(s1, nm["ln1"][0], nm["ln1"][1], M, d, eps)
+            if enc is not None:
+                o2, sv["x"] = self.attn_fwd(h, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias)
+                s2 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=h)
+                h, sv["lnx"] = self.ln_fwd(s2, nm["lnx"][0], nm["lnx"][1], M, d, eps)
+            s3, sv["f"] = self._ffn_fwd(h, M, d, F, nm["fc1"], nm["fc2"], act, h)
+            y, sv["ln2"] = self.ln_fwd(s3, nm["ln2"][0], nm["ln2"][1], M, d, eps)
+        else:
+            n1, sv["ln1"] = self.ln_fwd(x, nm["ln1"][0], nm["ln1"][1], M, d, eps, rms=rms)
+            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias)
+            x1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x)
+            if enc is not None:
+                nx, sv["lnx"] = self.ln_fwd(x1, nm["lnx"][0], nm["lnx"][1], M, d, eps, rms=rms)
+                o2, sv["x"] = self.attn_fwd(nx, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias)
+                x1 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=x1)
+            n2, sv["ln2"] = self.ln_fwd(x1, nm["ln2"][0], nm["ln2"][1], M, d, eps, rms=rms)
+            y, sv["f"] = self._ffn_fwd(n2, M, d, F, nm["fc1"], nm["fc2"], act, x1)
+        sv["dims"] = (B, T, d, H, F)
+        return y, sv
+
+    def _b(self, n):
+        return self.P(n) if n else None
+
+    def _oproj_bwd(self, dy, sv_attn, names, M, d):
+        """dy: grad wrt out_proj output; returns grad wrt attention output o."""
+        wn, bn = names["o"]
+        if self.tr(wn):
+            self.wgrad(dy, sv_attn["o"], self.G(wn), M, d, d, gb=self.G(bn) if bn else None)
+        do = self.new(M, d)
+        self.dgrad(dy, self.W(wn), do, M, d, d)
+        return do
+
+    def layer_bwd(self, dy, sv, nm, pre_ln, act, rms=False, denc=None):
+        B, T, d, H, F = sv["dims"]
+        M = B * T
+        if not pre_ln:
+            ds3 = self.ln_bwd(dy, sv["ln2"], nm["ln2"][0], nm["ln2"][1], M, d)
+            dh = self._ffn_bwd(ds3, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, ds3)
+            if "x" in sv:
+                ds2 = self.ln_bwd(dh, sv["lnx"], nm["lnx"][0], nm["lnx"][1], M, d)
+                do2 = self._oproj_bwd(ds2, sv["x"], nm["xattn"], M, d)
+                dh = self.attn_bwd(do2, sv["x"], nm["xattn"], dx_resid=ds2, dkv_accum=denc)
+            ds1 = self.ln_bwd(dh, sv["ln1"], nm["ln1"][0], nm["ln1"][1], M, d)
+            do = self._oproj_bwd(ds1, sv["a"], nm["attn"], M, d)
+            return self.attn_bwd(do, sv["a"], nm["attn"], dx_resid=ds1)
+        # pre-LN: y = x1 + ffn(LN2(x1)); x1 = x(+cross) + attn(LN1(x))
+        dn2 = self._ffn_bwd(dy, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, None)
+        dx1 = self.ln_bwd(dn2, sv["ln2"], nm["ln2"][0], nm["ln2"][1] if not rms else None, M, d, rms=rms, dres=dy)
+        if "x" in sv:
+            do2 = self._oproj_bwd(dx1, sv["x"], nm["xattn"], M, d)
+            dnx = self.attn_bwd(do2, sv["x"], nm["xattn"], dkv_accum=denc)
+            dx1 = self.ln_bwd(dnx, sv["lnx"], nm["lnx"][0], nm["lnx"][1] if not rms else None, M, d, rms=rms, dres=dx1)
+        do = self._oproj_bwd(dx1, sv["a"], nm["attn"], M, d)
+        dn1 = self.attn_bwd(do, sv["a"], nm["attn"])
+        return self.ln_bwd(dn1, sv["ln1"], nm["ln1"][0], nm["ln1"][1] if not rms else None, M, d, rms=rms, dres=dx1)
+
+    # ------------------------------------------------------------------ name tables
+    def _w2v2_layer_names(self, i):
+        p = f"{self.ep}encoder.layers.{i}."
+        a = {k: (p + f"attention.{n}.weight", p + f"attention.{n}.bias")
+             for k, n in (("q", "q_proj"), ("k", "k_proj"), ("v", "v_proj"), ("o", "out_proj"))}
+        return dict(attn=a, ln1=(p + "layer_norm.weight", p + "layer_norm.bias"),
+                    fc1=(p + "feed_forward.intermediate_dense.weight", p + "feed_forward.intermediate_dense.bias"),
+                    fc2=(p + "feed_forward.output_dense.weight", p + "feed_forward.output_dense.bias"),
+                    ln2=(p + "final_layer_norm.weight", p + "final_layer_norm.bias"))
+
+    def _bart_layer_names(self, side, i):
+        p = f"{self.lp}model.{side}.layers.{i}."
+
+        def att(a):
+            return {k: (p + f"{a}.{n}.weight", p + f"{a}.{n}.bias")
+                    for k, n in (("q", "q_proj"), ("k", "k_proj"), ("v", "v_proj"), ("o", "out_proj"))}
+        nm = dict(attn=att("self_attn"), ln1=(p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias"),
+                  fc1=(p + "fc1.weight", p + "fc1.bias"), fc2=(p + "fc2.weight", p + "fc2.bias"),
+                  ln2=(p + "final_layer_norm.weight", p + "final_layer_norm.bias"))
+        if side == "decoder":
+            nm["xattn"] = att("encoder_attn")
+            nm["lnx"] = (p + "encoder_attn_layer_norm.weight", p + "encoder_attn_layer_norm.bias")
+        return nm
+
+    def _t5_layer_names(self, side, i):
+        p = f"{self.lp}{side}.block.{i}.layer."
+
+        def att(a):
+            return {k: (p + f"{a}.{n}.weight", None) for k, n in (("q", "q"), ("k", "k"), ("v", "v"), ("o", "o"))}
+        ff = "2" if side == "decoder" else "1"
+        nm = dict(attn=att("0.SelfAttention"), ln1=(p + "0.layer_norm.weight", None),
+                  fc1=(p + f"{ff}.DenseReluDense.wi.weight", None), fc2=(p + f"{ff}.DenseReluDense.wo.weight", None),
+                  ln2=(p + f"{ff}.layer_norm.weight", None))
+        if side == "decoder":
+            nm["xattn"] = att("1.EncDecAttention")
+            nm["lnx"] = (p + "1.layer_norm.weight", None)
+        return nm
+
+    # ------------------------------------------------------------------ CNN feature extractor
+    def _conv_geom(self, N):
+        ec = self.ec
+        Ts, n = [], N
+        for k, s in zip(ec.conv_kernel, ec.conv_stride):
+            n = (n - k) // s + 1
+            Ts.append(n)
+        return Ts
+
+    def cnn_fwd(self, wave, B, N):
+        ec, ep = self.ec, self.ep
+        Ts = self._conv_geom(N)
+        group = ec.feat_extract_norm == "group"
+        nl = len(ec.conv_dim)
+        # `wave` is referenced by raw pointer from the conv0 descriptor until the very end of backward
+        sv = dict(Ts=Ts, B=B, N=N, y=[], pre=[], ln=[], wp=[None], wave=wave)
+        p0 = f"{ep}feature_extractor.conv_layers.0."
+        C0, T0 = ec.conv_dim[0], Ts[0]
+        cb0 = self.P(p0 + "conv.bias") if ec.conv_bias else None
+        y0 = self.new(B * T0, C0)
+        if group:
+            stats = self.new(B * C0 * 2, dt=torch.float64)
+            c0 = ops.conv0_params(wave, self.P(p0 + "conv.weight"), cb0, self.P(p0 + "layer_norm.weight"),
+                                  self.P(p0 + "layer_norm.bias"), stats, y0, B, N, C0, ec.conv_kernel[0],
+                                  ec.conv_stride[0], T0, True)
+            ops.conv0_fwd(c0, self.dt)
+            sv["c0"], sv["stats"] = c0, stats
+            sv["ln"].append(None)
+        else:
+            u0 = y0
+            c0 = ops.conv0_params(wave, self.P(p0 + "conv.weight"), cb0, None, None, None, u0, B, N, C0,
+                                  ec.conv_kernel[0], ec.conv_stride[0], T0, False)
+            ops.conv0_fwd(c0, self.dt)
+            sv["c0"] = c0
+            y0, lnsv = self.ln_fwd(u0, p0 + "layer_norm.weight", p0 + "layer_norm.bias", B * T0, C0, 1e-5, act=ACT_GELU)
+            sv["ln"].append(lnsv)
+        sv["y"].append(y0)
+        sv["pre"].append(None)
+        x, Cin, Tin = y0, C0, T0
+        for i in range(1, nl):
+            p = f"{ep}feature_extractor.conv_layers.{i}."
+            Co, k, s, To = ec.conv_dim[i], ec.conv_kernel[i], ec.conv_stride[i], Ts[i]
+            wp = self.new(Co, k * Cin)
+            ops.pack_conv_w(self.P(p + "conv.weight"), wp, Co, Cin, k, self.dt)
+            sv["wp"].append(wp)
+            cb = self.P(p + "conv.bias") if ec.conv_bias else None
+            av = view(s * Cin, To, Tin * Cin)
+            if group:
+                pre = self.new(B * To, Co)
+                y = self.lin(x, wp, cb, B * To, Co, k * Cin, act=ACT_GELU, aux_out=pre, av=av)
+                sv["pre"].append(pre)
+                sv["ln"].append(None)
+            else:
+                u = self.lin(x, wp, cb, B * To, Co, k * Cin, av=av)
+                y, lnsv = self.ln_fwd(u, p + "layer_norm.weight", p + "layer_norm.bias", B * To, Co, 1e-5, act=ACT_GELU)
+                sv["pre"].append(None)
+                sv["ln"].append(lnsv)
+            sv["y"].append(y)
+            x, Cin, Tin = y, Co, To
+        return x, sv
+
+    def cnn_bwd(self, dfeat, sv):
+        """dfeat: grad wrt the last conv layer's (activated) output [B*T_last, C]."""
+        ec, ep = self.ec, self.ep
+        Ts, B = sv["Ts"], sv["B"]
+        group = ec.feat_extract_norm == "group"
+        nl = len(ec.conv_dim)
+        PAD = 2
+        # dpre of layer i lives in a zero-padded per-clip buffer [B, T_i + 2*PAD, C_i]
+        i = nl - 1
+        Ci, Ti = ec.conv_dim[i], Ts[i]
+        dpre = self.persist_zeros(f"cnn_dpre{i}", B * (Ti + 2 * PAD), Ci)
+        padv = view(Ci, Ti, (Ti + 2 * PAD) * Ci, PAD * Ci)
+        if group:
+            ops.act_bwd(dfeat, sv["pre"][i], dpre, B * Ti, Ci, padv, ACT_GELU, self.dt)
+        else:
+            p = f"{ep}feature_extractor.conv_layers.{i}."
+            tmp = self.ln_bwd(dfeat, sv["ln"][i], p + "layer_norm.weight", p + "layer_norm.bias", B * Ti, Ci, act=ACT_GELU)
+            dpre.view(B, Ti + 2 * PAD, Ci)[:, PAD:PAD + Ti].copy_(tmp.view(B, Ti, Ci))
+        for i in range(nl - 1, 0, -1):
+            p = f"{ep}feature_extractor.conv_layers.{i}."
+            Co, Cin, k, s = ec.conv_dim[i], ec.conv_dim[i - 1], ec.conv_kernel[i], ec.conv_stride[i]
+            To, Tin = Ts[i], Ts[i - 1]
+            Tp = To + 2 * PAD
+            padv = view(Co, To, Tp * Co, PAD * Co)
+            x = sv["y"][i - 1]
+            xv = view(s * Cin, To, Tin * Cin)
+            if self.tr(p + "conv.weight"):
+                dwp = self.zeros(Co, k * Cin, dt=torch.float32)
+                self.wgrad(dpre, x, dwp, B * To, Co, k * Cin, dyv=padv, xv=xv)
+                ops.unpack_conv_dw(dwp, self.G(p + "conv.weight"), Co, Cin, k)
+                if ec.conv_bias:
+                    ops.colsum(dpre, self.G(p + "conv.bias"), B * Tp, Co, Co, self.dt)
+            # data gradient: one GEMM per residue r of the input position modulo the stride
+            if i - 1 >= 1 and group:
+                Tpp = Tin + 2 * PAD
+                dprev = self.persist_zeros(f"cnn_dpre{i - 1}", B * Tpp, Cin)
+                prev_off, prev_bs = PAD * Cin, Tpp * Cin
+            else:
+                dprev = self.new(B * Tin, Cin)
+                prev_off, prev_bs = 0, Tin * Cin
+            for r in range(s):
+                taps = list(range(r, k, s))
+                nj = len(taps)
+                U = (Tin - 1 - r) // s + 1 if Tin - 1 - r >= 0 else 0
+                if U <= 0:
+                    continue
+                if nj == 0:
+                    dprev.view(B, -1, Cin)[:, (prev_off // Cin) + r:(prev_off // Cin) + Tin:s].zero_()
+                    continue
+                av = view(Co, U, Tp * Co, (PAD - (nj - 1)) * Co)
+                bv = view(k * Cin, Co, -s * Cin, (r + (nj - 1) * s) * Cin)
+                cv = view(s * Cin, U, prev_bs, prev_off + r * Cin)
+                aux = sv["pre"][i - 1] if (i - 1 >= 1 and group) else None
+                ev = view(s * Cin, U, Tin * Cin, r * Cin) if aux is not None else None
+                ops.gemm(dpre, sv["wp"][i], dprev, B * U, Cin, nj * Co, self.dt, b_rc=True, av=av, bv=bv, cv=cv, ev=ev,
+                         aux_in=aux, act=ACT_GELU if aux is not None else ACT_NONE)
+            if i - 1 >= 1 and not group:
+                pp = f"{ep}feature_extractor.conv_layers.{i - 1}."
+                tmp = self.ln_bwd(dprev, sv["ln"][i - 1], pp + "layer_norm.weight", pp + "layer_norm.bias", B * Tin, Cin,
+                                  act=ACT_GELU)
+                Tpp = Tin + 2 * PAD
+                dprev = self.persist_zeros(f"cnn_dpre{i - 1}", B * Tpp, Cin)
+                dprev.view(B, Tpp, Cin)[:, PAD:PAD + Tin].copy_(tmp.view(B, Tin, Cin))
+            dpre = dprev
+        # layer 0
+        p0 = f"{ep}feature_extractor.conv_layers.0."
+        C0, T0 = ec.conv_dim[0], Ts[0]
+        if not self.tr(p0 + "conv.weight"):
+            return
+        c0 = sv["c0"]
+        if group:
+            bstats = self.new(B * C0 * 2, dt=torch.float64)
+            ops.conv0_bwd(c0, dpre, bstats, self.G(p0 + "conv.weight"), None, self.G(p0 + "layer_norm.weight"),
+                          self.G(p0 + "layer_norm.bias"), self.dt)
+        else:
+            du = self.ln_bwd(dpre, sv["ln"][0], p0 + "layer_norm.weight", p0 + "layer_norm.bias", B * T0, C0, act=ACT_GELU)
+            ops.conv0_bwd(c0, du, None, self.G(p0 + "conv.weight"), self.G(p0 + "conv.bias") if ec.conv_bias else None,
+                          None, None, self.dt)
+
+    # ------------------------------------------------------------------ positional conv embedding
+    def posconv_fwd(self, h, B, T):
+        ec, ep = self.ec, self.ep
+        d, K, G = ec.hidden_size, ec.num_conv_pos_embeddings, ec.num_conv_pos_embedding_groups
+        Cg, P, Tp = d // G, ec.num_conv_pos_embeddings // 2, T + ec.num_conv_pos_embeddings - 1
+        pre_n = f"{ep}encoder.pos_conv_embed.conv."
+        wp = self.new(G * Cg * K * Cg)
+        norm = self.new(K, dt=torch.float32)
+        ops.wn_fwd(self.P(pre_n + "parametrizations.weight.original1"), self.P(pre_n + "parametrizations.weight.original0"),
+                   wp, None, norm, d, Cg, K, self.dt)
+        xg = self.new(G * B * Tp * Cg)
+        ops.group_pack(h, xg, B, T, d, G, K, P, self.dt)
+        s = self.new(B * T, d)
+        pre = self.new(B * T, d)
+        ops.gemm(xg, wp, s, B * T, Cg, K * Cg, self.dt, av=view(Cg, T, Tp * Cg), bv=view(K * Cg), cv=view(d),
+                 bias=self.P(pre_n + "bias"), resid=h, aux_out=pre, act=ACT_GELU, nbatch=G, batch_a=B * Tp * Cg,
+                 batch_b=Cg * K * Cg, batch_c=Cg, batch_bias=Cg)
+        return s, dict(xg=xg, wp=wp, norm=norm, pre=pre, B=B, T=T)
+
+    def posconv_bwd(self, ds, sv):
+        ec, ep = self.ec, self.ep
+        B, T = sv["B"], sv["T"]
+        d, K, G = ec.hidden_size, ec.num_conv_pos_embeddings, ec.num_conv_pos_embedding_groups
+        Cg, P, Tp = d // G, K // 2, T + K - 1
+        pre_n = f"{ep}encoder.pos_conv_embed.conv."
+        dpre = self.new(B * T, d)
+        ops.act_bwd(ds, sv["pre"], dpre, B * T, d, view(d), ACT_GELU, self.dt)
+        v_n, g_n = pre_n + "parametrizations.weight.original1", pre_n + "parametrizations.weight.original0"
+        if self.tr(v_n, g_n, pre_n + "bias"):
+            ops.colsum(dpre, self.G(pre_n + "bias"), B * T, d, d, self.dt)
+            dwp = self.zeros(G * Cg * K * Cg, dt=torch.float32)
+            ops.gemm(dpre, sv["xg"], dwp, Cg, K * Cg, B * T, self.dt, a_rc=True, b_rc=True, av=view(d),
+                     bv=view(Cg, T, Tp * Cg), cv=view(K * Cg), out_f32=True, atomic=True,
+                     split_k=self._split(Cg, K * Cg, B * T), nbatch=G, batch_a=Cg, batch_b=B * Tp * Cg,
+                     batch_c=Cg * K * Cg)
+            scratch = self.new(K, dt=torch.float32)
+            ops.wn_bwd(dwp, self.P(v_n), self.P(g_n), sv["norm"], scratch, self.G(g_n), self.G(v_n), d, Cg, K)
+        dyg = self.new(G * B * Tp * Cg)
+        ops.group_pack(dpre, dyg, B, T, d, G, K, K - 1 - P, self.dt)
+        dh = self.new(B * T, d)
+        ops.gemm(dyg, sv["wp"], dh, B * T, Cg, K * Cg, self.dt, b_rc=True, av=view(Cg, T, Tp * Cg),
+                 bv=view(K * Cg, Cg, -Cg, (K - 1) * Cg), cv=view(d), resid=ds, nbatch=G, batch_a=B * Tp * Cg,
+                 batch_b=Cg * K * Cg, batch_c=Cg)
+        return dh
+
+    # ------------------------------------------------------------------ SpecAugment indices (host RNG)
+    def _spec_augment_rows(self, B, T):
+        """TF:models/wav2vec2/modeling_wav2vec2.py:101-218 (_compute_mask_indices), no attention mask."""
+        ec = self.ec
+        prob, length, mmin = ec.mask_time_prob, ec.mask_time_length, ec.mask_time_min_masks
+        if prob <= 0 or length >= T:
+            return None
+        eps = self.rng.random()
+        n_spans = max(int(prob * T / length + eps), mmin)
+        if n_spans * length > T:
+            n_spans = T // length
+        if n_spans <= 0:
+            return None
+        rows = []
+        for b in range(B):
+            starts = self.rng.choice(np.arange(T - (length - 1)), n_spans, replace=False)
+            idx = np.unique((starts[:, None] + np.arange(length)[None, :]).reshape(-1))
+            rows.append(idx[idx < T] + b * T)
+        return torch.from_numpy(np.concatenate(rows).astype(np.int32)).to(self.dev)
+
+    # ------------------------------------------------------------------ speech encoder
+    def speech_fwd(self, wave, B, N, training):
+        ec, ep = self.ec, self.ep
+        d, eps = ec.hidden_size, ec.layer_norm_eps
+        feat, cnn_sv = self.cnn_fwd(wave, B, N)
+        T = cnn_sv["Ts"][-1]
+        C = ec.conv_dim[-1]
+        M = B * T
+        sv = dict(cnn=cnn_sv, T=T, B=B)
+        if ec.feat_proj_layer_norm:
+            fn, sv["fp_ln"] = self.ln_fwd(feat, ep + "feature_projection.layer_norm.weight",
+                                          ep + "feature_projection.layer_norm.bias", M, C, eps)
+        else:
+            fn = feat
+        sv["fp_in"] = fn
+        h = self.lin(fn, self.W(ep + "feature_projection.projection.weight"), self.P(ep + "feature_projection.projection.bias"),
+                     M, d, C)
+        sv["mask_rows"] = None
+        if training and ec.apply_spec_augment and self.has(ep + "masked_spec_embed"):
+            rows = self._spec_augment_rows(B, T)
+            if rows is not None:
+                ops.mask_rows(h, rows, rows.numel(), self.P(ep + "masked_spec_embed"), d, self.dt)
+                sv["mask_rows"] = rows
+        s, sv["pc"] = self.posconv_fwd(h, B, T)
+        stable = ec.do_stable_layer_norm
+        if not stable:
+            x, sv["enc_ln"] = self.ln_fwd(s, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps)
+        else:
+            x = s
+        act = _act_id(ec.hidden_act)
+        sv["layers"] = []
+        hidden = [x]
+        for i in range(self.L):
+            if training and ec.layerdrop > 0 and self.rng.random() < ec.layerdrop:
+                sv["layers"].append(None)
+                hidden.append(x)
+                continue
+            x, lsv = self.layer_fwd(x, B, T, d, ec.num_attention_heads, ec.intermediate_size, self._w2v2_layer_names(i),
+                                    stable, act, eps)
+            sv["layers"].append(lsv)
+            hidden.append(x)
+        if stable:
+            x, sv["final_ln"] = self.ln_fwd(x, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps)
+            hidden[-1] = x
+        sv["hidden"] = hidden
+        return x, sv
+
+    def speech_bwd(self, dx, sv):
+        ec, ep = self.ec, self.ep
+        d = ec.hidden_size
+        B, T = sv["B"], sv["T"]
+        M = B * T
+        C = ec.conv_dim[-1]
+        stable = ec.do_stable_layer_norm
+        act = _act_id(ec.hidden_act)
+        if stable:
+            dx = self.ln_bwd(dx, sv["final_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
+        for i in range(self.L - 1, -1, -1):
+            if sv["layers"][i] is None:
+                continue
+            dx = self.layer_bwd(dx, sv["layers"][i], self._w2v2_layer_names(i), stable, act)
+        if not stable:
+            dx = self.ln_bwd(dx, sv["enc_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
+        dh = self.posconv_bwd(dx, sv["pc"])
+        if sv["mask_rows"] is not None:
+            rows = sv["mask_rows"]
+            me = ep + "masked_spec_embed"
+            ops.mask_rows_bwd(dh, rows, rows.numel(), self.G(me) if self.tr(me) else None, d, self.dt)
+        wn, bn = ep + "feature_projection.projection.weight", ep + "feature_projection.projection.bias"
+        if self.tr(wn):
+            self.wgrad(dh, sv["fp_in"], self.G(wn), M, d, C, gb=self.G(bn))
+        dfn = self.new(M, C)
+        self.dgrad(dh, self.W(wn), dfn, M, d, C)
+        if ec.feat_proj_layer_norm:
+            dfeat = self.ln_bwd(dfn, sv["fp_ln"], ep + "feature_projection.layer_norm.weight",
+                                ep + "feature_projection.layer_norm.bias", M, C)
+        else:
+            dfeat = dfn
+        if any(self.st.requires_grad(n) for n in self.st.offsets if n.startswith(ep + "feature_extractor.")):
+            self.cnn_bwd(dfeat, sv["cnn"])
+
+    # ------------------------------------------------------------------ length adapters + projection
+    def bridge_fwd(self, x, B, T):
+        d = self.ec.hidden_size
+        sv = dict(B=B, Ts=[T], xs=[], wps=[])
+        for i in range(self.downloop):
+            To = (T - 2) // 2 + 1
+            wp = self.new(d, 2 * d)
+            ops.pack_conv_w(self.P(f"length_adapters.{i}.weight"), wp, d, d, 2, self.dt)
+            y = self.lin(x, wp, self.P(f"length_adapters.{i}.bias"), B * To, d, 2 * d, av=view(2 * d, To, T * d))
+            sv["xs"].append(x)
+            sv["wps"].append(wp)
+            x, T = y, To
+            sv["Ts"].append(T)
+        dd = self.lc.d_model
+        sv["post_adapter"] = x
+        e = self.lin(x, self.W("enc_to_dec_proj.weight"), self.P("enc_to_dec_proj.bias"), B * T, dd, d)
+        return e, T, sv
+
+    def bridge_bwd(self, de, sv):
+        d, dd, B = self.ec.hidden_size, self.lc.d_model, sv["B"]
+        T = sv["Ts"][-1]
+        x = sv["post_adapter"]
+        if self.tr("enc_to_dec_proj.weight"):
+            self.wgrad(de, x, self.G("enc_to_dec_proj.weight"), B * T, dd, d, gb=self.G("enc_to_dec_proj.bias"))
+        dx = self.new(B * T, d)
+        self.dgrad(de, self.W("enc_to_dec_proj.weight"), dx, B * T, dd, d)
+        for i in range(self.downloop - 1, -1, -1):
+            Tin, To = sv["Ts"][i], sv["Ts"][i + 1]
+            xin, wp = sv["xs"][i], sv["wps"][i]
+            wn, bn = f"length_adapters.{i}.weight", f"length_adapters.{i}.bias"
+            if self.tr(wn):
+                dwp = self.zeros(d, 2 * d, dt=torch.float32)
+                self.wgrad(dx, xin, dwp, B * To, d, 2 * d, xv=view(2 * d, To, Tin * d), gb=self.G(bn))
+                ops.unpack_conv_dw(dwp, self.G(wn), d, d, 2)
+            dprev = self.persist_zeros(f"adapter_dx{i}", B * Tin, d)
+            # k == stride: the column matrix IS the input -> plain dgrad through the tap-major weight
+            self.dgrad(dx, wp, dprev, B * To, d, 2 * d, cv=view(2 * d, To, Tin * d))
+            dx = dprev
+        return dx
+
+    # ------------------------------------------------------------------ seq2seq LM
+    def _t5_bias(self, side, Tq, Tk):
+        """Relative-position bias [H, Tq, Tk] fp32 (TF:models/t5/modeling_t5.py:216-279).  Bucket indices are
+        integer host work; the gather from the [buckets, H] table is a pure index op."""
+        lc = self.lc
+        name = f"{self.lp}{side}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"
+        nb, md = lc.relative_attention_num_buckets, lc.relative_attention_max_distance
+        ctx = torch.arange(Tq)[:, None]
+        mem = torch.arange(Tk)[None, :]
+        rel = mem - ctx
+        bidir = side == "encoder"
+        ret = torch.zeros_like(rel)
+        n = nb
+        if bidir:
+            n //= 2
+            ret += (rel > 0).long() * n
+            rel = rel.abs()
+        else:
+            rel = -torch.min(rel, torch.zeros_like(rel))
+        max_exact = n // 2
+        small = rel < max_exact
+        large = max_exact + (torch.log(rel.float() / max_exact) / math.log(md / max_exact) * (n - max_exact)).long()
+        large = torch.min(large, torch.full_like(large, n - 1))
+        buckets = (ret + torch.where(small, rel, large)).to(self.dev)
+        table = self.P(name)                                   # [buckets, H] fp32
+        return table[buckets].permute(2, 0, 1).contiguous(), buckets
+
+    def lm_fwd(self, inputs_embeds, input_ids, dec_ids, B, S, Ld, training):
+        lc, lp = self.lc, self.lp
+        d = lc.d_model
+        t5 = lc.model_type == "t5"
+        pre_ln = lc.model_type in ("mbart", "t5")
+        act = _act_id(lc.activation_function)
+        sv = dict(B=B, S=S, Ld=Ld, t5=t5)
+        emb_name = lp + ("shared.weight" if t5 else "model.shared.weight")
+        escale = math.sqrt(d) if (lc.scale_embedding and not t5) else 1.0
+        sv["emb_name"], sv["escale"] = emb_name, escale
+        H, F = lc.encoder_attention_heads, lc.encoder_ffn_dim
+        # ---- text encoder
+        if inputs_embeds is None:
+            x = self.new(B * S, d)
+            ops.embed_fwd(input_ids, self.W(emb_name), x, B * S, d, escale, self.dt)
+            sv["enc_ids"] = input_ids
+        else:
+            x = inputs_embeds
+            sv["enc_ids"] = None
+        ebias = dbias = None
+        if t5:
+            if lc.is_gated_act:
+                raise NotImplementedError("gated T5 feed-forward is not on the SpeechMix path")
+            ebias, _ = self._t5_bias("encoder", S, S)
+            dbias, _ = self._t5_bias("decoder", Ld, Ld)
+            h = x
+            eps = lc.layer_norm_epsilon
+        else:
+            eps = 1e-5
+            pe = lp + "model.encoder."
+            h, sv["enc_emb_ln"] = self.ln_fwd(x, pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", B * S, d,
+                                              eps, pos=self.W(pe + "embed_positions.weight"), pos_period=S, pos_offset=2,
+                                              want_sum=True)
+        sv["enc_layers"] = []
+        for i in range(lc.encoder_layers):
+            nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
+            h, lsv = self.layer_fwd(h, B, S, d, H, F, nm, pre_ln, act, eps, scale=1.0 if t5 else None, rms=t5, bias=ebias)
+            sv["enc_layers"].append(lsv)
+        if t5:
+            h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "encoder.final_layer_norm.weight", None, B * S, d, eps, rms=True)
+        elif lc.model_type == "mbart":
+            h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "model.encoder.layer_norm.weight", lp + "model.encoder.layer_norm.bias",
+                                                B * S, d, eps)
+        enc = h
+        sv["enc_out"] = enc
+        # ---- decoder
+        y = self.new(B * Ld, d)
+        ops.embed_fwd(dec_ids, self.W(emb_name), y, B * Ld, d, escale, self.dt)
+        sv["dec_ids"] = dec_ids
+        Hd, Fd = lc.decoder_attention_heads, lc.decoder_ffn_dim
+        if not t5:
+            pd = lp + "model.decoder."
+            y, sv["dec_emb_ln"] = self.ln_fwd(y, pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", B * Ld, d,
+                                              eps, pos=self.W(pd + "embed_positions.weight"), pos_period=Ld, pos_offset=2,
+                                              want_sum=True)
+        sv["dec_layers"] = []
+        for i in range(lc.decoder_layers):
+            nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
+            y, lsv = self.layer_fwd(y, B, Ld, d, Hd, Fd, nm, pre_ln, act, eps, causal=True, scale=1.0 if t5 else None,
+                                    enc=enc, Tk=S, rms=t5, bias=dbias)
+            sv["dec_layers"].append(lsv)
+        if t5:
+            y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "decoder.final_layer_norm.weight", None, B * Ld, d, eps, rms=True)
+        elif lc.model_type == "mbart":
+            y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "model.decoder.layer_norm.weight", lp + "model.decoder.layer_norm.bias",
+                                                B * Ld, d, eps)
+        sv["dec_out"] = y
+        # ---- LM head (tied embedding) + final_logits_bias
+        V = lc.vocab_size
+        Vp = (V + 7) // 8 * 8
+        head = lp + "lm_head.weight" if self.has(lp + "lm_head.weight") else emb_name
+        sv["head"] = head
+        alpha = d ** -0.5 if (t5 and lc.tie_word_embeddings) else 1.0
+        sv["head_alpha"] = alpha
+        flb = self.st.module.get_buffer(lp + "final_logits_bias").view(-1) if not t5 else None
+        logits = self.new(B * Ld, Vp, dt=torch.float32)
+        ops.gemm(y, self.W(head), logits, B * Ld, V, d, self.dt, cv=view(Vp), bias=flb, out_f32=True, alpha=alpha)
+        sv["logits"], sv["V"], sv["Vp"] = logits, V, Vp
+        return logits, enc, sv
+
+    def lm_bwd(self, dlogits, sv, gscale):
+        """dlogits [B*Ld, Vp] compute dtype.  Returns grad wrt inputs_embeds [B*S, d] (or None for token input)."""
+        lc, lp = self.lc, self.lp
+        d, B, S, Ld, t5 = lc.d_model, sv["B"], sv["S"], sv["Ld"], sv["t5"]
+        pre_ln = lc.model_type in ("mbart", "t5")
+        act = _act_id(lc.activation_function)
+        V, Vp, head = sv["V"], sv["Vp"], sv["head"]
+        a = sv["head_alpha"] * gscale
+        Md, Ms = B * Ld, B * S
+        emb_name, escale = sv["emb_name"], sv["escale"]
+        lm_trainable = self.tr(head)
+        if lm_trainable:
+            self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a)
+        dy = self.new(Md, d)
+        self.dgrad(dlogits, self.W(head), dy, Md, V, d, av=view(Vp), alpha=a)
+        if t5:
+            dy = self.ln_bwd(dy, sv["dec_final_ln"], lp + "decoder.final_layer_norm.weight", None, Md, d, rms=True)
+        elif lc.model_type == "mbart":
+            dy = self.ln_bwd(dy, sv["dec_final_ln"], lp + "model.decoder.layer_norm.weight", lp + "model.decoder.layer_norm.bias",
+                             Md, d)
+        denc = [self.new(Ms, d), True]
+        for i in range(lc.decoder_layers - 1, -1, -1):
+            nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
+            dy = self.layer_bwd(dy, sv["dec_layers"][i], nm, pre_ln, act, rms=t5, denc=denc)
+            denc[1] = False
+        if not t5:
+            pd = lp + "model.decoder."
+            pos_n = pd + "embed_positions.weight"
+            dy = self.ln_bwd(dy, sv["dec_emb_ln"], pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", Md, d,
+                             dpos=self.G(pos_n) if self.tr(pos_n) else None, pos_period=Ld, pos_offset=2)
+        if self.tr(emb_name):
+            ops.embed_bwd(sv["dec_ids"], dy, self.G(emb_name), Md, d, escale, self.dt)
+        # ---- text encoder
+        dh = denc[0]
+        if t5:
+            dh = self.ln_bwd(dh, sv["enc_final_ln"], lp + "encoder.final_layer_norm.weight", None, Ms, d, rms=True)
+        elif lc.model_type == "mbart":
+            dh = self.ln_bwd(dh, sv["enc_final_ln"], lp + "model.encoder.layer_norm.weight", lp + "model.encoder.layer_norm.bias",
+                             Ms, d)
+        for i in range(lc.encoder_layers - 1, -1, -1):
+            nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
+            dh = self.layer_bwd(dh, sv["enc_layers"][i], nm, pre_ln, act, rms=t5)
+        if not t5:
+            pe = lp + "model.encoder."
+            pos_n = pe + "embed_positions.weight"
+            dh = self.ln_bwd(dh, sv["enc_emb_ln"], pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", Ms, d,
+                             dpos=self.G(pos_n) if self.tr(pos_n) else None, pos_period=S, pos_offset=2)
+        if sv["enc_ids"] is not None:
+            if self.tr(emb_name):
+                ops.embed_bwd(sv["enc_ids"], dh, self.G(emb_name), Ms, d, escale, self.dt)
+            return None
+        return dh
+
+    # ------------------------------------------------------------------ whole step
+    def forward(self, wave, dec_ids, labels, training=False, prompt_embeds=None):
+        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None."""
+        self.st.refresh_shadow()
+        B, N = wave.shape
+        Ld = dec_ids.shape[1]
+        x, ssv = self.speech_fwd(wave, B, N, training)
+        e, S, bsv = self.bridge_fwd(x, B, ssv["T"])
+        if prompt_embeds is not None:
+            raise NotImplementedError("input_text_prompt is not implemented in the HIP engine yet")
+        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training)
+        V, Vp = lsv["V"], lsv["Vp"]
+        M = B * Ld
+        argmax = self.new(M, dt=torch.int64)
+        loss = None
+        dlogits = None
+        if labels is not None:
+            loss = self.zeros(1, dt=torch.float32)
+            dlogits = self.new(M, Vp)
+            ops.cross_entropy(logits, labels.reshape(-1).contiguous(), loss, argmax, dlogits, M, V, Vp, Vp, self.dt)
+        else:
+            ops.cross_entropy(logits, None, None, argmax, None, M, V, Vp, Vp, self.dt)
+        self.saved = dict(speech=ssv, bridge=bsv, lm=lsv, dlogits=dlogits, B=B, Ld=Ld)
+        return dict(loss=loss, argmax=argmax.view(B, Ld), logits=logits, enc_last=x, lm_enc_last=enc, inputs_embeds=e,
+                    S=S, T=ssv["T"], post_adapter=bsv["post_adapter"], hidden=ssv["hidden"])
+
+    def backward(self, gscale=1.0, zero_grads=True):
+        sv = self.saved
+        if sv is None or sv["dlogits"] is None:
+            raise RuntimeError("backward() needs a forward() with labels")
+        if zero_grads:
+            self.st.grad.zero_()
+        de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale)
+        dx = self.bridge_bwd(de, sv["bridge"])
+        self.speech_bwd(dx, sv["speech"])
+        self.saved = None

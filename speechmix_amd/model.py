@@ -1,0 +1,375 @@
+"""Drop-in classes for the reference's model API (ref:speechmix/model.py:57-177, 180-193, 225-266).
+
+Same constructors, `forward()` signature, attributes and `state_dict` names as the reference (HF naming for
+the backbones), but the forward + backward arithmetic is the hand-scheduled HIP engine
+(`speechmix_amd.engine`).  `train.py` of the reference can therefore construct these classes from its CLI
+kwargs and hand them to `transformers.Trainer`: `model(**batch)["loss"].backward()` runs the engine's
+backward through one `torch.autograd.Function` and leaves `.grad` populated on every trainable parameter.
+
+Known reference defects that are NOT reproduced: `weights_sum` is a real registered
+parameter; `SpeechMixSelf.forward` accepts and forwards `text_input_ids`.
+"""
+from __future__ import annotations
+
+import math
+import os
+import types
+import warnings
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .configs import LMConfig, SpeechEncoderConfig, load_lm_config, load_speech_config
+from .engine import Engine
+from .params import (FlatStore, ParamTree, build_tree, init_lm, init_speech_encoder, spec_lm, spec_speech_encoder)
+
+_DTYPES = {"bf16": ops.BF16, "bfloat16": ops.BF16, "fp32": ops.F32, "float32": ops.F32, ops.BF16: ops.BF16,
+           ops.F32: ops.F32, torch.bfloat16: ops.BF16, torch.float32: ops.F32}
+
+
+def handle_decoder_input_none(decoder_config, batch=1, device="cpu"):
+    """ref:speechmix/model.py:11-12."""
+    return torch.tensor([[decoder_config.decoder_start_token_id]] * batch).to(device)
+
+
+def shift_tokens_right(input_ids: torch.Tensor, pad_token_id: int, decoder_start_token_id: int):
+    """ref:speechmix/model.py:15-23 (same argument meaning and error behaviour)."""
+    shifted_input_ids = input_ids.new_zeros(input_ids.shape)
+    shifted_input_ids[:, 1:] = input_ids[:, :-1].clone()
+    shifted_input_ids[:, 0] = decoder_start_token_id
+    assert pad_token_id is not None, "self.model.config.pad_token_id has to be defined."
+    shifted_input_ids.masked_fill_(shifted_input_ids == -100, pad_token_id)
+    return shifted_input_ids
+
+
+class _Out(dict):
+    """dict with attribute access (what callers of HF model outputs expect: out.logits / out['logits'])."""
+    __getattr__ = dict.get
+
+
+class SpeechEncoderModule(ParamTree):
+    """Owns the wav2vec2 / HuBERT parameters under HF names; `.config` mirrors the HF config object."""
+
+    def __init__(self, cfg: SpeechEncoderConfig):
+        super().__init__()
+        self.config = cfg
+
+
+class Seq2SeqLMModule(ParamTree):
+    """Owns the BART / mBART / T5 parameters under HF names.  Callable for inference the way the reference's
+    label-creation loop calls it (ref:train.py:18-34): `lm(input_ids=..., decoder_input_ids=...).logits`."""
+
+    def __init__(self, cfg: LMConfig):
+        super().__init__()
+        self.config = cfg
+        self._owner = None
+
+    def get_input_embeddings(self):
+        owner = self._owner() if self._owner else None
+        return owner.nlp_emb if owner is not None else None
+
+    def forward(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None, **_):
+        owner = self._owner()
+        return owner._lm_only(input_ids=input_ids, inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids,
+                              labels=labels)
+
+
+class TokenEmbedding(ParamTree):
+    """`nlp_emb` of the reference (ref:speechmix/model.py:124): the LM's input embedding, callable on ids.
+    Registered as a sub-module so that `nlp_emb.weight` appears in the state dict like in the reference."""
+
+    def __init__(self, weight, owner_ref):
+        super().__init__()
+        self.add("weight", weight)
+        self._owner = owner_ref
+
+    def forward(self, ids):
+        return self._owner()._embed_tokens(ids)
+
+
+class _StepFn(torch.autograd.Function):
+    """One autograd node for the whole fused step: forward = engine.forward, backward = engine.backward."""
+
+    @staticmethod
+    def forward(ctx, model, wave, dec_ids, labels, training, anchor, *params):
+        out = model.engine.forward(wave, dec_ids, labels, training=training)
+        ctx.model = model
+        ctx.n_params = len(params)
+        model._last = out
+        return out["loss"].view(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model = ctx.model
+        accumulate = model._grads_live()
+        model.engine.backward(gscale=float(gloss), zero_grads=not accumulate)
+        if ctx.n_params:
+            grads = tuple(model.store.g(n) if p.requires_grad else None for n, p in model.store.params.items())
+            return (None, None, None, None, None, None) + grads
+        model.store.publish_grads()
+        return (None, None, None, None, None, torch.zeros((), device=gloss.device))
+
+
+class SpeechMixEED(nn.Module):
+    def __init__(self, speech_model_config, nlp_model_config, share_layer_ratio=0, down_scale=8, weighted_sum=False,
+                 fixed_parameters=False,
+                 fixed_except=["layer_norm", "encoder_attn", 'enc_to_dec_proj', 'length_adapter', "layernorm_embedding",
+                               'attention', 'encoder'], **kwargs):
+        super().__init__()
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.compute_dtype = _DTYPES[kwargs.pop("compute_dtype", "bf16")]
+        seed = kwargs.pop("init_seed", 0)
+        enc_cfg, enc_ckpt = load_speech_config(speech_model_config)
+        lm_cfg, lm_ckpt = load_lm_config(nlp_model_config)
+        self.weighted_sum = weighted_sum
+
+        total_layers = enc_cfg.num_hidden_layers
+        print("Before layer sharing num_speech_encoder_layers", total_layers)
+        remove_layers = int(total_layers * share_layer_ratio) if share_layer_ratio != 0 else 0
+        self.num_speech_encoder_layers = total_layers - remove_layers
+        num_nlp_encoder_layers = lm_cfg.encoder_layers
+        print("After layer sharing ", "num_speech_encoder_layers", self.num_speech_encoder_layers,
+              "num_nlp_encoder_layers", num_nlp_encoder_layers, "share_layer_ratio", share_layer_ratio,
+              "remove_layers", remove_layers)
+
+        gen = torch.Generator().manual_seed(seed)
+        self.encoder_model = SpeechEncoderModule(enc_cfg)
+        build_tree(spec_speech_encoder(enc_cfg, self.num_speech_encoder_layers), device=self.device, tree=self.encoder_model)
+        init_speech_encoder(self.encoder_model, enc_cfg, gen)
+        self.decoder_model = Seq2SeqLMModule(lm_cfg)
+        spec, alias, buffers = spec_lm(lm_cfg)
+        build_tree(spec, alias, buffers, device=self.device, tree=self.decoder_model)
+        init_lm(self.decoder_model, lm_cfg, gen)
+        self.tokenizer = self._load_tokenizer(nlp_model_config)
+
+        # Downsample (ref:speechmix/model.py:89-98)
+        self.downsize = down_scale
+        self.downloop = int(math.log(self.downsize, 2))
+        d = enc_cfg.hidden_size
+        if self.downsize > 1:
+            self.length_adapters = nn.Sequential(*[self._adapter(d, gen) for _ in range(self.downloop)])
+        else:
+            self.length_adapters = nn.Sequential(nn.Identity())
+        # HF-twin semantics: L+1 hidden states (ref:speechmix/hf_model.py:268-270)
+        self.weights_sum = nn.Parameter(torch.zeros(self.num_speech_encoder_layers + 1, device=self.device))
+        self.enc_to_dec_proj = ParamTree()
+        k = math.sqrt(1.0 / d)
+        self.enc_to_dec_proj.add("weight", nn.Parameter(
+            torch.empty(lm_cfg.d_model, d).uniform_(-k, k, generator=gen).to(self.device)))
+        self.enc_to_dec_proj.add("bias", nn.Parameter(torch.empty(lm_cfg.d_model).uniform_(-k, k, generator=gen).to(self.device)))
+        if enc_ckpt:
+            self._load_backbone(self.encoder_model, enc_ckpt)
+        if lm_ckpt:
+            self._load_backbone(self.decoder_model, lm_ckpt)
+
+        self.custom_modules(**kwargs)
+        if fixed_parameters:
+            self.encoder_model.eval()
+            self.decoder_model.eval()
+            for xcoder in [self.encoder_model.named_parameters, self.decoder_model.named_parameters]:
+                for name, param in xcoder():
+                    if param.requires_grad:
+                        param.requires_grad = any(k in name for k in fixed_except)
+
+        import weakref
+        lm_t5 = lm_cfg.model_type == "t5"
+        shared = self.decoder_model.shared.weight if lm_t5 else self.decoder_model.model.shared.weight
+        self.nlp_emb = TokenEmbedding(shared, weakref.ref(self))
+        list_no_grad, list_grad = [], []
+        for name, param in self.named_parameters():
+            (list_grad if param.requires_grad else list_no_grad).append(name)
+        self.speech_encoder_layer = self.num_speech_encoder_layers
+        self.nlp_encoder_layer = num_nlp_encoder_layers
+        self.list_grad = list_grad
+        self.list_no_grad = list_no_grad
+
+        # ---- MI355X engine -----------------------------------------------------------------------
+        self.decoder_model._owner = weakref.ref(self)
+        self.autograd_param_inputs = bool(kwargs.get("autograd_param_inputs", False))
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self._last = None
+        self.store = None
+        self.engine = None
+        if self.device.type == "cuda":
+            self._build_engine()
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def _adapter(d, gen):
+        m = ParamTree()
+        k = math.sqrt(1.0 / (d * 2))
+        m.add("weight", nn.Parameter(torch.empty(d, d, 2).uniform_(-k, k, generator=gen)))
+        m.add("bias", nn.Parameter(torch.empty(d).uniform_(-k, k, generator=gen)))
+        return m
+
+    @staticmethod
+    def _load_tokenizer(spec):
+        if isinstance(spec, str) and os.path.isdir(spec):
+            try:
+                from transformers import AutoTokenizer
+                return AutoTokenizer.from_pretrained(spec)
+            except Exception as e:  # tokenizer files are optional for the compute path
+                warnings.warn(f"no tokenizer loaded from {spec}: {e}")
+        return None
+
+    @staticmethod
+    def _load_backbone(tree, ckpt_dir):
+        path = os.path.join(ckpt_dir, "model.safetensors")
+        if not os.path.exists(path):
+            return
+        from safetensors.torch import load_file
+        sd = load_file(path)
+        own = dict(tree.state_dict())
+        fixed = {}
+        for k, v in sd.items():
+            for pre in ("wav2vec2.", "hubert."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            k = k.replace("pos_conv_embed.conv.weight_g", "pos_conv_embed.conv.parametrizations.weight.original0")
+            k = k.replace("pos_conv_embed.conv.weight_v", "pos_conv_embed.conv.parametrizations.weight.original1")
+            if k in own and tuple(own[k].shape) == tuple(v.shape):
+                fixed[k] = v
+        tree.load_state_dict(fixed, strict=False)
+
+    def _build_engine(self):
+        self.to(self.device)
+        tdt = ops.torch_dtype(self.compute_dtype)
+        self.store = FlatStore(self, self.device, tdt)
+        self.engine = Engine(self.store, self.encoder_model.config, self.decoder_model.config, self.compute_dtype,
+                             self.num_speech_encoder_layers, self.downsize)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if getattr(self, "store", None) is not None:
+            self.store.rebind()
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        if self.store is not None:
+            self.store.invalidate()
+        return out
+
+    def _grads_live(self):
+        for p in self.store.params.values():
+            if p.requires_grad:
+                return p.grad is not None
+        return False
+
+    # ------------------------------------------------------------------ reference hooks
+    def custom_modules(self, **kwargs):
+        return None
+
+    def _embed_tokens(self, ids):
+        """decoder_model.get_input_embeddings()(ids) (ref:speechmix/model.py:124): [*, L] int64 -> [*, L, d]."""
+        lc = self.decoder_model.config
+        ids = ids.to(self.device)
+        flat = ids.reshape(-1).contiguous()
+        out = torch.empty(flat.numel(), lc.d_model, dtype=ops.torch_dtype(self.compute_dtype), device=self.device)
+        self.store.refresh_shadow()
+        name = "decoder_model." + ("shared.weight" if lc.model_type == "t5" else "model.shared.weight")
+        scale = math.sqrt(lc.d_model) if (lc.scale_embedding and lc.model_type != "t5") else 1.0
+        ops.embed_fwd(flat, self.store.w(name), out, flat.numel(), lc.d_model, scale, self.compute_dtype)
+        return out.view(*ids.shape, lc.d_model)
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError("speechmix_amd needs an MI355X (HIP) device: the compute path has no CPU fallback")
+
+    def _prep_wave(self, input_values):
+        if isinstance(input_values, (list, tuple)):
+            input_values = torch.stack([torch.as_tensor(v) for v in input_values])
+        return input_values.to(self.device, torch.float32).contiguous()
+
+    def _lm_only(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None):
+        """LM forward without the speech side (label creation / SpeechMixSelf text pass)."""
+        self._need_engine()
+        eng, lc = self.engine, self.decoder_model.config
+        self.store.refresh_shadow()
+        if decoder_input_ids is None and labels is not None:
+            decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
+        dec = decoder_input_ids.to(self.device)
+        B, Ld = dec.shape
+        if input_ids is not None:
+            ids = input_ids.to(self.device)
+            S = ids.shape[1]
+            logits, enc, sv = eng.lm_fwd(None, ids.reshape(-1).contiguous(), dec.reshape(-1).contiguous(), B, S, Ld, False)
+        else:
+            emb = inputs_embeds.to(self.device, ops.torch_dtype(self.compute_dtype)).contiguous()
+            S = emb.shape[1]
+            logits, enc, sv = eng.lm_fwd(emb.view(B * S, -1), None, dec.reshape(-1).contiguous(), B, S, Ld, False)
+        V = sv["V"]
+        out = _Out(logits=logits.view(B, Ld, -1)[:, :, :V], encoder_last_hidden_state=enc.view(B, S, -1).float())
+        if labels is not None:
+            loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            am = torch.empty(B * Ld, dtype=torch.int64, device=self.device)
+            ops.cross_entropy(logits, labels.to(self.device).reshape(-1).contiguous(), loss, am, None, B * Ld, V, sv["Vp"],
+                              sv["Vp"], self.compute_dtype)
+            out["loss"] = loss.view(())
+        return out
+
+    def cal_loss(self, inputs_embeds=None, attention_mask=None, decoder_input_ids=None, labels=None):
+        """ref:speechmix/model.py:132-137 - LM on `inputs_embeds` (no speech side, no autograd)."""
+        return self._lm_only(inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids, labels=labels)
+
+    # ------------------------------------------------------------------ forward (ref:speechmix/model.py:139-177)
+    def forward(self, input_values, input_text_prompt=None, decoder_input_ids=None, labels=None,
+                return_model_detail=False):
+        self._need_engine()
+        lc = self.decoder_model.config
+        wave = self._prep_wave(input_values)
+        if decoder_input_ids is None and labels is None:
+            decoder_input_ids = handle_decoder_input_none(lc, len(wave), device=self.device)
+        elif decoder_input_ids is None and labels is not None:
+            decoder_input_ids = shift_tokens_right(labels.to(self.device), lc.pad_token_id, lc.decoder_start_token_id)
+        if self.weighted_sum:
+            raise NotImplementedError("weighted_sum=True is not implemented in the HIP engine yet (off in all baseline configs)")
+        if input_text_prompt is not None:
+            raise NotImplementedError("input_text_prompt is not implemented in the HIP engine yet")
+        dec = decoder_input_ids.to(self.device).contiguous()
+        lab = labels.to(self.device).contiguous() if labels is not None else None
+        training = self.training and self.encoder_model.training
+        return_dict = {}
+        want_grad = torch.is_grad_enabled() and lab is not None and len(self.list_grad) > 0
+        if want_grad:
+            params = tuple(self.store.params.values()) if self.autograd_param_inputs else ()
+            loss = _StepFn.apply(self, wave, dec, lab, training, self._anchor, *params)
+            out = self._last
+        else:
+            out = self.engine.forward(wave, dec, lab, training=False)
+            loss = out["loss"].view(()) if out["loss"] is not None else None
+            self.engine.saved = None
+        B, Ld = dec.shape
+        if return_model_detail:
+            d = self.encoder_model.config.hidden_size
+            T, S, dd = out["T"], out["S"], lc.d_model
+            return_dict["shape_before_length_adapter"] = torch.Size((B, T, d))
+            return_dict["shape_before_enc_dec_projector"] = torch.Size((B, S, d))
+            return_dict["shape_after_enc_dec_projector"] = torch.Size((B, S, dd))
+            # extensions for parity checks: the reference hides these behind argmax
+            V = lc.vocab_size
+            return_dict["raw_logits"] = out["logits"].view(B, Ld, -1)[:, :, :V]
+            return_dict["encoder_last_hidden_state"] = out["enc_last"].view(B, T, d).float()
+            return_dict["inputs_embeds"] = out["inputs_embeds"].view(B, S, dd).float()
+            return_dict["lm_encoder_last_hidden"] = out["lm_enc_last"].view(B, S, dd).float()
+        return_dict["logits"] = out["argmax"]
+        if loss is not None:
+            return_dict["loss"] = loss
+        return return_dict
+
+
+class SpeechMixFixed(SpeechMixEED):
+    """ref:speechmix/model.py:180-193 - requires_grad flags only."""
+
+    def custom_modules(self, fixed_speech=False, fixed_nlp=True, **kwargs):
+        print(fixed_speech, fixed_nlp, kwargs)
+        self.encoder_model.eval()
+        self.decoder_model.eval()
+        if fixed_speech:
+            for name, param in self.encoder_model.named_parameters():
+                param.requires_grad = False
+        if fixed_nlp:
+            for name, param in self.decoder_model.named_parameters():
+                param.requires_grad = False

@@ -1,0 +1,204 @@
+"""Thin, validating Python wrappers over the C-ABI kernels in libspeechmix_hip.so.
+
+Every function takes torch tensors only as *device memory handles* (data_ptr + shape); all arithmetic
+happens in the hand-written HIP kernels.  There is no PyTorch/CPU fallback: a missing library, a
+non-GPU tensor or a non-zero return code raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32  # noqa: F401
+
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def torch_dtype(dt):
+    return _TORCH_DT[dt]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("speechmix_amd kernels need GPU tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def view(ld, rows_per_batch=0, batch_stride=0, off=0):
+    return L.RowView(batch_stride, ld, off, rows_per_batch, 0)
+
+
+def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=None, bias=None, resid=None,
+         aux_out=None, aux_in=None, act=ACT_NONE, out_f32=False, atomic=False, split_k=1, alpha=1.0, nbatch=1,
+         batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None):
+    """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements."""
+    p = L.GemmParams()
+    p.A, p.B, p.C = _ptr(a), _ptr(b), _ptr(c)
+    p.bias, p.resid, p.aux_out, p.aux_in = _ptr(bias), _ptr(resid), _ptr(aux_out), _ptr(aux_in)
+    p.a = av if av is not None else view(K if not a_rc else M)
+    p.b = bv if bv is not None else view(K if not b_rc else N)
+    p.c = cv if cv is not None else view(N)
+    p.e = ev if ev is not None else p.c
+    p.batch_a, p.batch_b, p.batch_c, p.batch_bias = batch_a, batch_b, batch_c, batch_bias
+    p.batch_e = batch_c if batch_e is None else batch_e
+    p.M, p.N, p.K, p.a_rc, p.b_rc = M, N, K, int(a_rc), int(b_rc)
+    p.act, p.out_f32, p.atomic = act, int(out_f32), int(atomic)
+    p.nbatch, p.split_k, p.tr_mode, p.alpha = nbatch, split_k, tr_mode, alpha
+    L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+
+
+def norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dtype, eps=1e-5, rms=False, act=ACT_NONE, pos=None, pos_period=0,
+             pos_offset=0, xsum_out=None):
+    p = L.NormParams(_ptr(x), _ptr(pos), _ptr(xsum_out), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                     M, D, pos_period, pos_offset, int(rms), act, eps)
+    L.check(L.lib().smx_norm_fwd(C.byref(p), dtype, _stream()), "smx_norm_fwd")
+
+
+def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms=False, act=ACT_NONE, dres=None,
+             dpos=None, pos_period=0, pos_offset=0):
+    p = L.NormBwdParams(_ptr(dy), _ptr(x), _ptr(dres), _ptr(dx), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
+                        _ptr(dgamma), _ptr(dbeta), _ptr(dpos), M, D, pos_period, pos_offset, int(rms), act)
+    L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
+
+
+class AttnDesc:
+    """Strided description of Q/K/V/O living inside fused projection buffers (element units)."""
+
+    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None):
+        self.p = L.AttnParams()
+        p = self.p
+        p.B, p.H, p.Tq, p.Tk, p.D, p.causal, p.scale = B, H, Tq, Tk, D, int(causal), scale
+        p.bias = _ptr(bias)
+        self._keep = [bias]
+
+    def set(self, name, tensor, elem_off, batch_stride, ld):
+        """name in Q K V O dO dQ dK dV"""
+        setattr(self.p, name, _ptr(tensor) + elem_off * tensor.element_size())
+        pre = {"Q": "q", "K": "k", "V": "v", "O": "o", "dO": "do", "dQ": "dq", "dK": "dk", "dV": "dv"}[name]
+        setattr(self.p, pre + "_bs", batch_stride)
+        setattr(self.p, pre + "_ld", ld)
+        self._keep.append(tensor)
+
+
+def attention_fwd(desc, lse, dtype):
+    desc.p.lse = _ptr(lse)
+    L.check(L.lib().smx_attention_fwd(C.byref(desc.p), dtype, _stream()), "smx_attention_fwd")
+
+
+def attention_bwd(desc, lse, delta, dtype, dbias=None):
+    desc.p.lse, desc.p.delta, desc.p.dbias = _ptr(lse), _ptr(delta), _ptr(dbias)
+    L.check(L.lib().smx_attention_bwd(C.byref(desc.p), dtype, _stream()), "smx_attention_bwd")
+
+
+def conv0_params(wave, w, cbias, gamma, beta, stats, y, B, N, Cc, k, stride, T0, group, eps=1e-5):
+    p = L.Conv0Params()
+    p.wave, p.w, p.cbias, p.gamma, p.beta, p.stats, p.y = _ptr(wave), _ptr(w), _ptr(cbias), _ptr(gamma), _ptr(beta), \
+        _ptr(stats), _ptr(y)
+    p.B, p.N, p.C, p.k, p.stride, p.T0, p.group, p.eps = B, N, Cc, k, stride, T0, int(group), eps
+    return p
+
+
+def conv0_fwd(p, dtype):
+    L.check(L.lib().smx_conv0_fwd(C.byref(p), dtype, _stream()), "smx_conv0_fwd")
+
+
+def conv0_bwd(p, dy, bstats, dw, dcbias, dgamma, dbeta, dtype):
+    p.dy, p.bstats, p.dw, p.dcbias, p.dgamma, p.dbeta = _ptr(dy), _ptr(bstats), _ptr(dw), _ptr(dcbias), _ptr(dgamma), \
+        _ptr(dbeta)
+    L.check(L.lib().smx_conv0_bwd(C.byref(p), dtype, _stream()), "smx_conv0_bwd")
+
+
+def cast_from_f32(src, dst, n, dtype):
+    L.check(L.lib().smx_cast_from_f32(C.c_void_p(_ptr(src)), C.c_void_p(_ptr(dst)), C.c_longlong(n), dtype, _stream()),
+            "smx_cast_from_f32")
+
+
+def cast_to_f32(src, dst, n, dtype):
+    L.check(L.lib().smx_cast_to_f32(C.c_void_p(_ptr(src)), C.c_void_p(_ptr(dst)), C.c_longlong(n), dtype, _stream()),
+            "smx_cast_to_f32")
+
+
+def pack_conv_w(w, out, Co, Ci, k, dtype):
+    L.check(L.lib().smx_pack_conv_w(C.c_void_p(_ptr(w)), C.c_void_p(_ptr(out)), Co, Ci, k, dtype, _stream()),
+            "smx_pack_conv_w")
+
+
+def unpack_conv_dw(dwp, dw, Co, Ci, k):
+    L.check(L.lib().smx_unpack_conv_dw(C.c_void_p(_ptr(dwp)), C.c_void_p(_ptr(dw)), Co, Ci, k, _stream()),
+            "smx_unpack_conv_dw")
+
+
+def embed_fwd(ids, table, out, M, D, scale, dtype):
+    L.check(L.lib().smx_embed_fwd(C.c_void_p(_ptr(ids)), C.c_void_p(_ptr(table)), C.c_void_p(_ptr(out)), M, D,
+                                  C.c_float(scale), dtype, _stream()), "smx_embed_fwd")
+
+
+def embed_bwd(ids, dy, dtable, M, D, scale, dtype):
+    L.check(L.lib().smx_embed_bwd(C.c_void_p(_ptr(ids)), C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(dtable)), M, D,
+                                  C.c_float(scale), dtype, _stream()), "smx_embed_bwd")
+
+
+def colsum(x, out, M, N, ld, dtype, alpha=1.0):
+    L.check(L.lib().smx_colsum(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_longlong(ld), C.c_float(alpha),
+                               dtype, _stream()), "smx_colsum")
+
+
+def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, gscale=1.0, lse=None):
+    p = L.CEParams(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(argmax), _ptr(dlogits), _ptr(lse), M, V, ldl, ldd, gscale)
+    L.check(L.lib().smx_cross_entropy(C.byref(p), dtype, _stream()), "smx_cross_entropy")
+
+
+def add(a, b, out, n, dtype):
+    L.check(L.lib().smx_add(C.c_void_p(_ptr(a)), C.c_void_p(_ptr(b)), C.c_void_p(_ptr(out)), C.c_longlong(n), dtype,
+                            _stream()), "smx_add")
+
+
+def mask_rows(x, rows, nrows, emb, D, dtype):
+    L.check(L.lib().smx_mask_rows(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(rows)), nrows, C.c_void_p(_ptr(emb)), D, dtype,
+                                  _stream()), "smx_mask_rows")
+
+
+def mask_rows_bwd(dx, rows, nrows, demb, D, dtype):
+    L.check(L.lib().smx_mask_rows_bwd(C.c_void_p(_ptr(dx)), C.c_void_p(_ptr(rows)), nrows, C.c_void_p(_ptr(demb)), D,
+                                      dtype, _stream()), "smx_mask_rows_bwd")
+
+
+def group_pack(x, xg, B, T, Cc, G, K, pad_front, dtype):
+    L.check(L.lib().smx_group_pack(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(xg)), B, T, Cc, G, K, pad_front, dtype,
+                                   _stream()), "smx_group_pack")
+
+
+def wn_fwd(v, g, wp, wf, norm, Cc, Cg, K, dtype):
+    L.check(L.lib().smx_wn_fwd(C.c_void_p(_ptr(v)), C.c_void_p(_ptr(g)), C.c_void_p(_ptr(wp)), C.c_void_p(_ptr(wf)),
+                               C.c_void_p(_ptr(norm)), Cc, Cg, K, dtype, _stream()), "smx_wn_fwd")
+
+
+def wn_bwd(dwp, v, g, norm, scratch, dg, dv, Cc, Cg, K):
+    L.check(L.lib().smx_wn_bwd(C.c_void_p(_ptr(dwp)), C.c_void_p(_ptr(v)), C.c_void_p(_ptr(g)), C.c_void_p(_ptr(norm)),
+                               C.c_void_p(_ptr(scratch)), C.c_void_p(_ptr(dg)), C.c_void_p(_ptr(dv)), Cc, Cg, K,
+                               _stream()), "smx_wn_bwd")
+
+
+def sumsq(g, n, out):
+    L.check(L.lib().smx_sumsq(C.c_void_p(_ptr(g)), C.c_longlong(n), C.c_void_p(_ptr(out)), _stream()), "smx_sumsq")
+
+
+def optimizer_step(p, g, m, v, shadow, gnorm_sq, n, lr, kind="adamw", beta1=0.9, beta2=0.999, eps=1e-8,
+                   weight_decay=0.0, step=1, grad_scale=1.0, max_grad_norm=0.0):
+    o = L.OptParams()
+    o.p, o.g, o.m, o.v, o.shadow, o.gnorm_sq = _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), _ptr(gnorm_sq)
+    o.n, o.lr, o.beta1, o.beta2, o.eps, o.weight_decay = n, lr, beta1, beta2, eps, weight_decay
+    o.bias_c1, o.bias_c2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    o.grad_scale, o.max_grad_norm, o.kind = grad_scale, max_grad_norm, 1 if kind == "adamw" else 0
+    L.check(L.lib().smx_optimizer_step(C.byref(o), _stream()), "smx_optimizer_step")
+
+
+def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):
+    L.check(L.lib().smx_act_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(pre)), C.c_void_p(_ptr(dx)), M, N,
+                                C.byref(out_view), act, dtype, _stream()), "smx_act_bwd")

@@ -23,7 +23,8 @@ def run(A, B, Cout, M, N, K, a_rc, b_rc, dtype, av=None, bv=None, cv=None, bias=
     p.aux_out = aux_out.data_ptr() if aux_out is not None else None
     p.aux_in = aux_in.data_ptr() if aux_in is not None else None
     p.a = av or view(A.stride(0)); p.b = bv or view(B.stride(0)); p.c = cv or view(Cout.stride(0))
-    p.batch_a, p.batch_b, p.batch_c, p.batch_bias = ba, bb, bc, 0
+    p.e = p.c
+    p.batch_a, p.batch_b, p.batch_c, p.batch_bias, p.batch_e = ba, bb, bc, 0, bc
     p.M, p.N, p.K, p.a_rc, p.b_rc = M, N, K, a_rc, b_rc
     p.act, p.out_f32, p.atomic, p.nbatch, p.split_k, p.tr_mode, p.alpha = act, out_f32, atomic, nbatch, split_k, tr_mode, alpha
     rc = lib.smx_gemm(C.byref(p), dtype, stream())
