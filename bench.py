@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds/second per SpeechMixEED training step (wav2vec2-base -> bart-base).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A step = forward + backward + RCCL gradient all-reduce + clip + optimizer update of this framework's HIP path
+over one synthetic batch (BASELINE.json configs[1]: B=32 x 10 s @ 16 kHz per GPU, down_scale 2, 32 label
+tokens, bf16 compute, random-init weights).  Weak scaling: per-GPU batch fixed.  Rank 0 prints
+ONE JSON line.  `roofline` = the dominant GEMM kernel variant timed live with HIP events on the launch stream
+inside the timed region; `cpu_baseline` = the CPU oracle (port of the reference path) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 10.0
+SAMPLES = 160000
+LABEL_LEN = 32
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md (measured 2495)
+
+
+def synth_batch(B, vocab, rank, device):
+    """N(0, 0.1^2) clipped to [-1,1], seed 1234+rank; labels uniform in [4,V), seed 4321+rank, eos last."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    wave = (torch.randn(B, SAMPLES, generator=g) * 0.1).clamp_(-1, 1)
+    g2 = torch.Generator().manual_seed(4321 + rank)
+    labels = torch.randint(4, vocab, (B, LABEL_LEN), generator=g2)
+    labels[:, -1] = 2
+    return wave.to(device), labels.to(device)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (CPU port of the reference path) fwd+bwd on one 10 s clip; audio-s/s on this host's cores."""
+    from oracle import speechmix_oracle as O
+    from speechmix_amd.configs import LMConfig, SpeechEncoderConfig
+    from speechmix_amd.params import build_tree, init_lm, init_speech_encoder, spec_lm, spec_speech_encoder
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    ec, lc = SpeechEncoderConfig(), LMConfig()
+    gen = torch.Generator().manual_seed(0)
+    enc = build_tree(spec_speech_encoder(ec, ec.num_hidden_layers)); init_speech_encoder(enc, ec, gen)
+    spec, alias, buffers = spec_lm(lc)
+    lm = build_tree(spec, alias, buffers); init_lm(lm, lc, gen)
+    sd = {"encoder_model." + k: v for k, v in enc.state_dict().items()}
+    sd.update({"decoder_model." + k: v for k, v in lm.state_dict().items()})
+    d = ec.hidden_size
+    sd["length_adapters.0.weight"] = torch.randn(d, d, 2, generator=gen) * 0.02
+    sd["length_adapters.0.bias"] = torch.zeros(d)
+    sd["enc_to_dec_proj.weight"] = torch.randn(lc.d_model, d, generator=gen) * 0.02
+    sd["enc_to_dec_proj.bias"] = torch.zeros(lc.d_model)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()
+              and not k.endswith(("embed_tokens.weight", "lm_head.weight"))}
+    wave, labels = synth_batch(1, lc.vocab_size, 0, "cpu")
+    times = []
+    t_start = time.perf_counter()
+    for it in range(8):
+        t0 = time.perf_counter()
+        out = O.speechmix_eed_forward(leaves, ec.to_dict(), lc.to_dict(), wave, labels=labels, down_scale=2)
+        out["loss"].backward()
+        for v in leaves.values():
+            v.grad = None
+        times.append(time.perf_counter() - t0)
+        if it >= 1 and time.perf_counter() - t_start > seconds_budget:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return {"value": round(CLIP_SECONDS / t, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "sample": f"1 clip x 10 s, fwd+bwd fp32 (no optimizer), median of {len(times[1:] or times)} after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from speechmix_amd import ops
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.trainer import StepRunner
+
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", share_layer_ratio=0, down_scale=2,
+                             compute_dtype="bf16", init_seed=0)
+    model.eval()          # deterministic step: dropout / layerdrop / SpecAugment off (reported as dropout p=0)
+    runner = StepRunner(model, lr=4e-5, optimizer="adamw", max_grad_norm=1.0)
+    B = args.batch
+    wave, labels = synth_batch(B, model.decoder_model.config.vocab_size, rank, device)
+
+    for _ in range(args.warmup):
+        loss = runner.step(wave, labels)
+    prof = None
+    if not args.no_profile:
+        prof = ops.GemmProfile()
+        ops.GEMM_PROFILE = prof
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner.step(wave, labels)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * B * CLIP_SECONDS * args.steps / elapsed
+        line = {"metric": "audio-seconds/sec per training step, wav2vec2-base->bart-base", "value": round(value, 1),
+                "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "SpeechMixEED wav2vec2-base + bart-base, 32 x 10 s clips/GPU, down_scale=2, "
+                                       "32 label tokens, fwd+bwd+allreduce+clip+AdamW, dropout p=0",
+                           "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
+                "final_loss": round(final_loss, 4)}
+        if prof is not None:
+            summ = prof.summary()
+            dom = max(summ, key=lambda k: summ[k]["total_ms"])
+            d = summ[dom]
+            line["roofline"] = {"kernel": ops.GemmProfile.NAMES[dom], "bound": "mfma", "achieved": round(d["tflops"], 1),
+                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "avg_launch_us": round(d["avg_us"], 2), "launches": d["launches"]}
+            line["gemm_variants"] = {ops.GemmProfile.NAMES[k]: {"tflops": round(v["tflops"], 1),
+                                                                  "ms_per_step": round(v["total_ms"] / args.steps, 3),
+                                                                  "launches_per_step": v["launches"] // args.steps}
+                                     for k, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

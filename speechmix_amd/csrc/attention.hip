@@ -451,6 +451,7 @@ static int attn_check(const SmxAttnParams& p, int dtype) {
 }
 
 extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxAttnParams p = *pp;
     int rc = attn_check(p, dtype);
     if (rc) return rc;
@@ -467,6 +468,7 @@ extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t
 }
 
 extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxAttnParams p = *pp;
     int rc = attn_check(p, dtype);
     if (rc) return rc;

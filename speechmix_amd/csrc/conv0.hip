@@ -273,6 +273,7 @@ static int conv0_check(const SmxConv0Params& p) {
 }
 
 extern "C" int smx_conv0_fwd(const SmxConv0Params* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxConv0Params p = *pp;
     int rc = conv0_check(p);
     if (rc) return rc;
@@ -290,6 +291,7 @@ extern "C" int smx_conv0_fwd(const SmxConv0Params* pp, int dtype, hipStream_t st
 
 // group mode: needs `stats` from the forward; accumulates dw, dgamma, dbeta.  plain mode: dy is du.
 extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxConv0Params p = *pp;
     int rc = conv0_check(p);
     if (rc) return rc;

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
 }
 
 extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxGemmParams p = *pp;
     if (p.M <= 0 || p.N <= 0 || p.K < 0) return SMX_EINVAL;
     if (p.nbatch < 1) p.nbatch = 1;

@@ -17,6 +17,7 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
         for (long long j = i; j < n; ++j) Cvt<T>::st(dst + j, src[j]);
 }
 extern "C" int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (n <= 0) return SMX_OK;
     long long blocks = (n / 8 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -35,6 +36,7 @@ __global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict_
     for (; i < n; i += stride) dst[i] = Cvt<T>::ld(src + i);
 }
 extern "C" int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (n <= 0) return SMX_OK;
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -56,6 +58,7 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 extern "C" int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     const long long n = (long long)Co * Ci * k;
     int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(pack_conv_w_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w, (bf16_t*)out, Co, Ci, k);
@@ -72,6 +75,7 @@ __global__ void unpack_conv_dw_kernel(const float* __restrict__ dwp, float* __re
     }
 }
 extern "C" int smx_unpack_conv_dw(const float* dwp, float* dw, int Co, int Ci, int k, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     const long long n = (long long)Co * Ci * k;
     int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(unpack_conv_dw_kernel, dim3(blocks), dim3(256), 0, stream, dwp, dw, Co, Ci, k);
@@ -97,6 +101,7 @@ __global__ void embed_fwd_kernel(const long long* __restrict__ ids, const T* __r
 }
 extern "C" int smx_embed_fwd(const long long* ids, const void* table, void* out, int M, int D, float scale, int dtype,
                              hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (M <= 0 || (D & 7)) return SMX_EINVAL;
     dim3 grid((M + 3) / 4);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, (const bf16_t*)table, (bf16_t*)out, M, D, scale);
@@ -120,6 +125,7 @@ __global__ void embed_bwd_kernel(const long long* __restrict__ ids, const T* __r
 }
 extern "C" int smx_embed_bwd(const long long* ids, const void* dy, float* dtable, int M, int D, float scale, int dtype,
                              hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (M <= 0 || (D & 7)) return SMX_EINVAL;
     dim3 grid((M + 3) / 4);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream, ids, (const bf16_t*)dy, dtable, M, D, scale);
@@ -159,6 +165,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     }
 }
 extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (M <= 0 || N <= 0 || (ld & 7)) return SMX_EINVAL;
     int gy = (M + 63) / 64;
     if (gy > 64) gy = 64;
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
     }
 }
 extern "C" int smx_cross_entropy(const SmxCEParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxCEParams p = *pp;
     if (p.M <= 0 || p.V <= 0 || p.ldl < p.V) return SMX_EINVAL;
     if (p.dlogits && p.ldd < p.V) return SMX_EINVAL;
@@ -259,6 +267,7 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
     }
 }
 extern "C" int smx_add(const void* a, const void* b, void* out, long long n, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (n <= 0 || (n & 7)) return SMX_EINVAL;
     long long blocks = (n / 8 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -279,6 +288,7 @@ __global__ void mask_rows_kernel(T* __restrict__ x, const int* __restrict__ rows
     for (int c = threadIdx.x; c < D; c += blockDim.x) Cvt<T>::st(dst + c, emb[c]);
 }
 extern "C" int smx_mask_rows(void* x, const int* rows, int nrows, const float* emb, int D, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (nrows <= 0) return SMX_OK;
     if (dtype == SMX_BF16) hipLaunchKernelGGL(mask_rows_kernel<bf16_t>, dim3(nrows), dim3(256), 0, stream, (bf16_t*)x, rows, nrows, emb, D);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(mask_rows_kernel<float>, dim3(nrows), dim3(256), 0, stream, (float*)x, rows, nrows, emb, D);
@@ -297,6 +307,7 @@ __global__ void mask_rows_bwd_kernel(T* __restrict__ dx, const int* __restrict__
     }
 }
 extern "C" int smx_mask_rows_bwd(void* dx, const int* rows, int nrows, float* demb, int D, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (nrows <= 0) return SMX_OK;
     if (dtype == SMX_BF16) hipLaunchKernelGGL(mask_rows_bwd_kernel<bf16_t>, dim3(nrows), dim3(256), 0, stream, (bf16_t*)dx, rows, nrows, demb, D);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(mask_rows_bwd_kernel<float>, dim3(nrows), dim3(256), 0, stream, (float*)dx, rows, nrows, demb, D);
@@ -326,6 +337,7 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ p
 }
 extern "C" int smx_act_bwd(const void* dy, const void* pre, void* dx, int M, int N, const SmxRowView* ov, int act, int dtype,
                            hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (M <= 0 || (N & 7)) return SMX_EINVAL;
     const long long n = (long long)M * (N / 8);
     int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(SmxNormBwdParams p) {
 }
 
 extern "C" int smx_norm_fwd(const SmxNormParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxNormParams p = *pp;
     if (p.M <= 0 || p.D <= 0 || p.D > 64 * 8 * LN_NCH || (p.D & 7)) return SMX_EINVAL;
     if (p.pos && p.pos_period <= 0) return SMX_EINVAL;
@@ -213,6 +214,7 @@ extern "C" int smx_norm_fwd(const SmxNormParams* pp, int dtype, hipStream_t stre
 }
 
 extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxNormBwdParams p = *pp;
     if (p.M <= 0 || p.D <= 0 || p.D > 64 * 8 * LN_NCH || (p.D & 7)) return SMX_EINVAL;
     if (p.dpos && p.pos_period <= 0) return SMX_EINVAL;

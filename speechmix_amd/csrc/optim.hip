@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 }
 // out (one float, zeroed here) = sum g^2
 extern "C" int smx_sumsq(const float* g, long long n, float* out, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     hipMemsetAsync(out, 0, sizeof(float), stream);
     if (n <= 0) return SMX_OK;
     long long blocks = (n / 4 + 255) / 256;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void opt_kernel(SmxOptParams o) {
     }
 }
 extern "C" int smx_optimizer_step(const SmxOptParams* op, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxOptParams o = *op;
     if (o.n <= 0) return SMX_OK;
     if (o.kind == 1 && (!o.m || !o.v)) return SMX_EINVAL;

@@ -27,6 +27,7 @@ __global__ void group_pack_kernel(const T* __restrict__ x, T* __restrict__ xg, i
 }
 extern "C" int smx_group_pack(const void* x, void* xg, int B, int T, int C, int G, int K, int pad_front, int dtype,
                               hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (C % G || (C / G) % 8) return SMX_EINVAL;
     const int Tp = T + K - 1;
     const long long n = (long long)G * B * Tp * (C / G / 8);
@@ -63,6 +64,7 @@ __global__ void wn_pack_kernel(const float* __restrict__ v, const float* __restr
 }
 extern "C" int smx_wn_fwd(const float* v, const float* g, void* wp, void* wf, float* norm, int C, int Cg, int K, int dtype,
                           hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     hipLaunchKernelGGL(wn_norm_kernel, dim3(K), dim3(256), 0, stream, v, norm, C, Cg, K);
     const long long n = (long long)C * Cg * K;
     int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
@@ -100,6 +102,7 @@ __global__ void wn_bwd_apply_kernel(const float* __restrict__ dwp, const float* 
 }
 extern "C" int smx_wn_bwd(const float* dwp, const float* v, const float* g, const float* norm, float* scratch_s, float* dg,
                           float* dv, int C, int Cg, int K, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
     hipLaunchKernelGGL(wn_bwd_dot_kernel, dim3(K), dim3(256), 0, stream, dwp, v, scratch_s, C, Cg, K);
     const long long n = (long long)C * Cg * K;
     int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);

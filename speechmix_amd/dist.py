@@ -1,0 +1,98 @@
+"""Data-parallel gradient reduction for the flat gradient buffer (RCCL over xGMI on MI355X, gloo on CPU).
+
+The reference gets data parallelism implicitly from HF Trainer -> accelerate -> DistributedDataParallel
+(TF:trainer.py:720-737): a bucketed sum-all-reduce of every trainable gradient.  Here the
+gradients already live in ONE flat fp32 buffer (params.FlatStore), so a bucket is just a contiguous range of
+it.  Buckets are declared per backward *stage* (LM, bridge, each speech-encoder layer, front end); as soon
+as the engine reports a stage finished, its ranges are all-reduced on a side HIP stream while the compute
+stream keeps running the rest of backward.  Parameters that received no gradient this step (layerdrop,
+frozen sets) simply contribute zeros, which keeps every rank's collective sequence identical.
+One process per GPU; no collective on the forward path (pure data parallel: each clip is independent).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def stage_ranges(offsets: Dict[str, Tuple[int, int, tuple]], num_speech_layers: int, max_bucket_elems: int = 64 << 20):
+    """Contiguous flat ranges per backward stage, in the order backward completes them."""
+    def span(pred):
+        sel = [(o, o + n) for name, (o, n, _) in offsets.items() if pred(name)]
+        if not sel:
+            return []
+        sel.sort()
+        out = [list(sel[0])]
+        for a, b in sel[1:]:
+            if a - out[-1][1] <= 4096:       # merge across alignment padding
+                out[-1][1] = max(out[-1][1], b)
+            else:
+                out.append([a, b])
+        chunks = []
+        for a, b in out:
+            while b - a > max_bucket_elems:
+                chunks.append((a, a + max_bucket_elems))
+                a += max_bucket_elems
+            chunks.append((a, b))
+        return chunks
+
+    stages = [("lm", span(lambda n: n.startswith("decoder_model.")))]
+    stages.append(("bridge", span(lambda n: n.startswith(("length_adapters.", "enc_to_dec_proj.", "weights_sum")))))
+    for i in range(num_speech_layers - 1, -1, -1):
+        pre = f"encoder_model.encoder.layers.{i}."
+        stages.append((f"enc_layer{i}", span(lambda n, pre=pre: n.startswith(pre))))
+    stages.append(("frontend", span(lambda n: n.startswith("encoder_model.") and ".encoder.layers." not in n
+                                    and not n.startswith("encoder_model.encoder.layers."))))
+    return stages
+
+
+class GradReducer:
+    def __init__(self, flat_grad: torch.Tensor, stages, group=None):
+        self.g = flat_grad
+        self.stages = dict(stages)
+        self.order = [s for s, _ in stages]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.cuda and self.world > 1 else None
+        self._done = set()
+        covered = sorted(r for rs in self.stages.values() for r in rs)
+        for (a0, b0), (a1, b1) in zip(covered[:-1], covered[1:]):
+            if b0 > a1:
+                raise RuntimeError("overlapping reduction buckets")
+
+    def begin_step(self):
+        self._done.clear()
+
+    def stage_done(self, name: str):
+        """Called by the engine on the compute stream right after the stage's last gradient kernel."""
+        if self.world == 1 or name in self._done or name not in self.stages:
+            self._done.add(name)
+            return
+        self._done.add(name)
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                for a, b in self.stages[name]:
+                    dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            for a, b in self.stages[name]:
+                dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+
+    def finish(self):
+        """Reduce whatever has not been reported yet and make the compute stream wait for the side stream."""
+        for name in self.order:
+            if name not in self._done:
+                self.stage_done(name)
+        if self.cuda and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+def shard_batch(n_items: int, rank: int, world: int):
+    """Even split of a global batch across ranks (ref semantics: DistributedSampler without padding)."""
+    per = n_items // world
+    return rank * per, (rank + 1) * per

@@ -46,6 +46,11 @@ class Engine:
         self._persist: Dict[str, torch.Tensor] = {}
         self.saved = None
         self.rng = np.random.default_rng(0)
+        self.stage_cb = None      # callable(stage_name): gradient ranges of that stage are final (dist.GradReducer)
+
+    def _stage(self, name):
+        if self.stage_cb is not None:
+            self.stage_cb(name)
 
     # ------------------------------------------------------------------ buffers / parameter access
     def new(self, *shape, dt=None):
@@ -574,9 +579,9 @@ class Engine:
         if stable:
             dx = self.ln_bwd(dx, sv["final_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
         for i in range(self.L - 1, -1, -1):
-            if sv["layers"][i] is None:
-                continue
-            dx = self.layer_bwd(dx, sv["layers"][i], self._w2v2_layer_names(i), stable, act)
+            if sv["layers"][i] is not None:
+                dx = self.layer_bwd(dx, sv["layers"][i], self._w2v2_layer_names(i), stable, act)
+            self._stage(f"enc_layer{i}")
         if not stable:
             dx = self.ln_bwd(dx, sv["enc_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
         dh = self.posconv_bwd(dx, sv["pc"])
@@ -830,6 +835,9 @@ class Engine:
         if zero_grads:
             self.st.grad.zero_()
         de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale)
+        self._stage("lm")
         dx = self.bridge_bwd(de, sv["bridge"])
+        self._stage("bridge")
         self.speech_bwd(dx, sv["speech"])
+        self._stage("frontend")
         self.saved = None

@@ -50,7 +50,51 @@ def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=N
     p.M, p.N, p.K, p.a_rc, p.b_rc = M, N, K, int(a_rc), int(b_rc)
     p.act, p.out_f32, p.atomic = act, int(out_f32), int(atomic)
     p.nbatch, p.split_k, p.tr_mode, p.alpha = nbatch, split_k, tr_mode, alpha
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = prof.events()
+        e0.record()
+        L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+        e1.record()
+        prof.add((int(a_rc), int(b_rc)), e0, e1, 2.0 * M * N * K * nbatch)
+        return
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+
+
+class GemmProfile:
+    """Live per-launch timing of the GEMM kernel variants with HIP events on the launch stream (bench.py).
+    Variants: (a_rc, b_rc) = (0,0) forward, (0,1) data gradient, (1,1) weight gradient."""
+    NAMES = {(0, 0): "gemm_bf16_kernel<KC,KC> (fwd)", (0, 1): "gemm_bf16_kernel<KC,RC> (dgrad)",
+             (1, 1): "gemm_bf16_kernel<RC,RC> (wgrad)", (1, 0): "gemm_bf16_kernel<RC,KC>"}
+
+    def __init__(self):
+        self.pool, self.used, self.recs = [], 0, []
+
+    def events(self):
+        if self.used + 2 > len(self.pool):
+            self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(256))
+        e = self.pool[self.used], self.pool[self.used + 1]
+        self.used += 2
+        return e
+
+    def add(self, key, e0, e1, flops):
+        self.recs.append((key, e0, e1, flops))
+
+    def summary(self):
+        """-> {variant: dict(launches, total_ms, avg_us, flops, tflops)}; call after a device synchronize."""
+        out = {}
+        for key, e0, e1, fl in self.recs:
+            d = out.setdefault(key, dict(launches=0, total_ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["total_ms"] / d["launches"]
+            d["tflops"] = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["total_ms"] > 0 else 0.0
+        return out
+
+
+GEMM_PROFILE = None
 
 
 def norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dtype, eps=1e-5, rms=False, act=ACT_NONE, pos=None, pos_period=0,

@@ -1,0 +1,82 @@
+"""Native training-step driver: forward + backward + gradient all-reduce + clipping + optimizer update.
+
+What HF `Trainer.training_step` + accelerate/DDP + the optimizer do around the reference model
+(TF:trainer.py:1892-1963; clip to max_grad_norm, optimizer step, zero_grad), done here
+without autograd and without per-tensor launches: the engine writes gradients into the flat buffer,
+`dist.GradReducer` all-reduces stage ranges on a side stream while backward continues, and the update is
+one fused launch per contiguous trainable range (which also refreshes the bf16 compute copies).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .dist import GradReducer, stage_ranges
+
+
+def trainable_ranges(store) -> List[Tuple[int, int]]:
+    """Maximal runs of consecutive trainable parameters in the flat buffer (alignment gaps are merged)."""
+    items = sorted((o, o + n, store.requires_grad(name)) for name, (o, n, _) in store.offsets.items())
+    out: List[List[int]] = []
+    prev_trainable = False
+    for a, b, tr in items:
+        if tr:
+            if out and prev_trainable:
+                out[-1][1] = b
+            else:
+                out.append([a, b])
+        prev_trainable = tr
+    return [(a, b) for a, b in out]
+
+
+class StepRunner:
+    def __init__(self, model, lr=4e-5, optimizer="adamw", betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 max_grad_norm=1.0, momentum=0.0):
+        model._need_engine()
+        self.model, self.store, self.engine = model, model.store, model.engine
+        self.kind = optimizer
+        self.lr, self.betas, self.eps, self.wd, self.max_grad_norm, self.momentum = lr, betas, eps, weight_decay, \
+            max_grad_norm, momentum
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        n = self.store.total
+        dev = self.store.device
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev) if (optimizer == "adamw" or momentum > 0) else None
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev) if optimizer == "adamw" else None
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = 0
+        self.ranges = trainable_ranges(self.store)
+        self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, model.num_speech_encoder_layers))
+        self.engine.stage_cb = self.reducer.stage_done
+        self.store.external_updates = False          # this runner keeps the bf16 compute copies fresh itself
+        self.store.refresh_shadow(force=True)
+
+    def step(self, input_values, labels, decoder_input_ids=None):
+        """One optimizer step on this rank's shard.  Returns the (device) loss tensor of this rank."""
+        from .model import shift_tokens_right
+        m, eng, st = self.model, self.engine, self.store
+        lc = m.decoder_model.config
+        wave = m._prep_wave(input_values)
+        labels = labels.to(st.device)
+        if decoder_input_ids is None:
+            decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
+        self.reducer.begin_step()
+        out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(), training=m.training)
+        eng.backward(gscale=1.0, zero_grads=True)
+        self.reducer.finish()
+        self.t += 1
+        inv_world = 1.0 / self.world
+        clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
+        if clip > 0:
+            ops.sumsq(st.grad, st.total, self.gnorm_sq)
+        sh = None if st.shadow is st.master else st.shadow
+        for a, b in self.ranges:
+            ops.optimizer_step(st.master[a:b], st.grad[a:b], self.m[a:b] if self.m is not None else None,
+                               self.v[a:b] if self.v is not None else None, sh[a:b] if sh is not None else None,
+                               self.gnorm_sq if clip > 0 else None, b - a, self.lr, kind=self.kind,
+                               beta1=self.betas[0] if self.kind == "adamw" else self.momentum, beta2=self.betas[1],
+                               eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=inv_world, max_grad_norm=clip)
+        st.mark_shadow_fresh()
+        return out["loss"]
