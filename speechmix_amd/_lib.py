@@ -6,6 +6,8 @@ raises, and every op wrapper raises RuntimeError on a non-zero return code.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must be imported BEFORE the shared object: one HIP runtime per process - torch's)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeechmix_hip.so")
 
@@ -58,7 +60,7 @@ class NormParams(C.Structure):
 class NormBwdParams(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dres", C.c_void_p), ("dx", C.c_void_p),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dpos", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dpos", C.c_void_p), ("partials", C.c_void_p),
                 ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
                 ("rms", C.c_int), ("act", C.c_int)]
 
@@ -81,7 +83,7 @@ class Conv0Params(C.Structure):
                 ("bstats", C.c_void_p), ("dw", C.c_void_p), ("dcbias", C.c_void_p), ("dgamma", C.c_void_p),
                 ("dbeta", C.c_void_p),
                 ("B", C.c_int), ("N", C.c_int), ("C", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("T0", C.c_int),
-                ("group", C.c_int), ("eps", C.c_float)]
+                ("group", C.c_int), ("eps", C.c_float), ("tiles_per_block", C.c_int)]
 
 
 class CEParams(C.Structure):

@@ -29,6 +29,7 @@ struct SmxConv0Params {
     int B, N, C, k, stride, T0;
     int group;            // 1: GroupNorm+GELU fused, 0: plain conv
     float eps;
+    int tiles_per_block;  // set by the launchers: consecutive time tiles handled by one block (reduction kernels)
 };
 
 __device__ __forceinline__ void load_w8(const SmxConv0Params& p, int c0, float w[8][C0_MAXK], float cb[8]) {
@@ -48,22 +49,26 @@ __device__ __forceinline__ void stage_wave(const SmxConv0Params& p, float* sx, i
     }
 }
 
-// pass 1 (group mode): per-(b,c) sum / sumsq of u = conv(x)
+// pass 1 (group mode): per-(b,c) sum / sumsq of u = conv(x).  A block walks `tiles_per_block` time tiles with
+// register accumulators, reduces its 4 waves through LDS and issues ONE fp64 atomic pair per channel.
 __global__ __launch_bounds__(256) void conv0_stats_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
     __shared__ float red[4][64][16];
-    const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
+    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    stage_wave(p, sx, b, t0);
-    __syncthreads();
-    for (int cb0 = 0; cb0 < p.C; cb0 += 512) {
-        const int c0 = cb0 + lane * 8;
-        float s[8], q[8];
+    const int c0 = lane * 8;
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
+    float s[8], q[8], w[8][C0_MAXK], cb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    if (c0 < p.C) load_w8(p, c0, w, cb);
+    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
+        const int t0 = tile * C0_TT;
+        __syncthreads();
+        stage_wave(p, sx, b, t0);
+        __syncthreads();
         if (c0 < p.C) {
-            float w[8][C0_MAXK], cb[8];
-            load_w8(p, c0, w, cb);
             for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
                 const float* x = sx + tt * p.stride;
 #pragma unroll
@@ -76,19 +81,18 @@ __global__ __launch_bounds__(256) void conv0_stats_kernel(SmxConv0Params p) {
                 }
             }
         }
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[wv][lane][j] = s[j]; red[wv][lane][8 + j] = q[j]; }
-        __syncthreads();
-        if (wv == 0 && c0 < p.C) {
+    for (int j = 0; j < 8; ++j) { red[wv][lane][j] = s[j]; red[wv][lane][8 + j] = q[j]; }
+    __syncthreads();
+    if (wv == 0 && c0 < p.C) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float ss = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
-                const float qq = red[0][lane][8 + j] + red[1][lane][8 + j] + red[2][lane][8 + j] + red[3][lane][8 + j];
-                atomicAdd(p.stats + ((long long)b * p.C + c0 + j) * 2, (double)ss);
-                atomicAdd(p.stats + ((long long)b * p.C + c0 + j) * 2 + 1, (double)qq);
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float ss = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+            const float qq = red[0][lane][8 + j] + red[1][lane][8 + j] + red[2][lane][8 + j] + red[3][lane][8 + j];
+            atomicAdd(p.stats + ((long long)b * p.C + c0 + j) * 2, (double)ss);
+            atomicAdd(p.stats + ((long long)b * p.C + c0 + j) * 2 + 1, (double)qq);
         }
-        __syncthreads();
     }
 }
 
@@ -110,33 +114,31 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(SmxConv0Params p) {
     stage_wave(p, sx, b, t0);
     __syncthreads();
     T* Y = reinterpret_cast<T*>(p.y) + (long long)b * p.T0 * p.C;
-    for (int cb0 = 0; cb0 < p.C; cb0 += 512) {
-        const int c0 = cb0 + lane * 8;
-        if (c0 >= p.C) continue;
-        float w[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8];
-        load_w8(p, c0, w, cb);
+    const int c0 = lane * 8;
+    if (c0 >= p.C) return;
+    float w[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8];
+    load_w8(p, c0, w, cb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f;
+        if (p.group) {
+            mean_rstd(p, b, c0 + j, mu[j], rs[j]);
+            gm[j] = p.gamma[c0 + j];
+            bt[j] = p.beta[c0 + j];
+        }
+    }
+    for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
+        const float* x = sx + tt * p.stride;
+        float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f;
-            if (p.group) {
-                mean_rstd(p, b, c0 + j, mu[j], rs[j]);
-                gm[j] = p.gamma[c0 + j];
-                bt[j] = p.beta[c0 + j];
-            }
-        }
-        for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
-            const float* x = sx + tt * p.stride;
-            float o[8];
+            float u = cb[j];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float u = cb[j];
-#pragma unroll
-                for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
-                if (p.group) u = act_fwd((u - mu[j]) * rs[j] * gm[j] + bt[j], SMX_ACT_GELU);
-                o[j] = u;
-            }
-            store8(Y + (long long)(t0 + tt) * p.C + c0, o);
+            for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
+            if (p.group) u = act_fwd((u - mu[j]) * rs[j] * gm[j] + bt[j], SMX_ACT_GELU);
+            o[j] = u;
         }
+        store8(Y + (long long)(t0 + tt) * p.C + c0, o);
     }
 }
 
@@ -145,25 +147,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
     __shared__ float red[4][64][16];
-    const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
+    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    stage_wave(p, sx, b, t0);
-    __syncthreads();
+    const int c0 = lane * 8;
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
     const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C;
-    for (int cb0 = 0; cb0 < p.C; cb0 += 512) {
-        const int c0 = cb0 + lane * 8;
-        float s1[8], s2[8];
+    float s1[8], s2[8], w[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (c0 < p.C) {
+        load_w8(p, c0, w, cb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mean_rstd(p, b, c0 + j, mu[j], rs[j]);
+            gm[j] = p.gamma[c0 + j];
+            bt[j] = p.beta[c0 + j];
+        }
+    }
+    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
+        const int t0 = tile * C0_TT;
+        __syncthreads();
+        stage_wave(p, sx, b, t0);
+        __syncthreads();
         if (c0 < p.C) {
-            float w[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8];
-            load_w8(p, c0, w, cb);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                mean_rstd(p, b, c0 + j, mu[j], rs[j]);
-                gm[j] = p.gamma[c0 + j];
-                bt[j] = p.beta[c0 + j];
-            }
             for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
                 const float* x = sx + tt * p.stride;
                 float d[8];
@@ -180,19 +187,18 @@ __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(SmxConv0Params p) 
                 }
             }
         }
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[wv][lane][j] = s1[j]; red[wv][lane][8 + j] = s2[j]; }
-        __syncthreads();
-        if (wv == 0 && c0 < p.C) {
+    for (int j = 0; j < 8; ++j) { red[wv][lane][j] = s1[j]; red[wv][lane][8 + j] = s2[j]; }
+    __syncthreads();
+    if (wv == 0 && c0 < p.C) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
-                const float c = red[0][lane][8 + j] + red[1][lane][8 + j] + red[2][lane][8 + j] + red[3][lane][8 + j];
-                atomicAdd(p.bstats + ((long long)b * p.C + c0 + j) * 2, (double)a);
-                atomicAdd(p.bstats + ((long long)b * p.C + c0 + j) * 2 + 1, (double)c);
-            }
+        for (int j = 0; j < 8; ++j) {
+            const float a = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+            const float c = red[0][lane][8 + j] + red[1][lane][8 + j] + red[2][lane][8 + j] + red[3][lane][8 + j];
+            atomicAdd(p.bstats + ((long long)b * p.C + c0 + j) * 2, (double)a);
+            atomicAdd(p.bstats + ((long long)b * p.C + c0 + j) * 2 + 1, (double)c);
         }
-        __syncthreads();
     }
 }
 
@@ -209,65 +215,87 @@ __global__ void conv0_bwd_affine_kernel(SmxConv0Params p) {
     if (p.dgamma) atomicAdd(p.dgamma + c, (float)g);
 }
 
-// backward pass 2: du (through GroupNorm) then dW[c][t] += sum du * x[stride*t' + t]
+// backward pass 2: du (through GroupNorm) then dW[c][t] += sum du * x[stride*t' + t].  Register accumulators
+// across `tiles_per_block` tiles, LDS reduction over the 4 waves, one fp32 atomic per (channel, tap) per block.
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
-    const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
+    __shared__ float red[4][64][8];
+    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    stage_wave(p, sx, b, t0);
-    __syncthreads();
+    const int c0 = lane * 8;
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
     const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C;
     const float invT = 1.0f / (float)p.T0;
-    for (int cb0 = 0; cb0 < p.C; cb0 += 512) {
-        const int c0 = cb0 + lane * 8;
-        if (c0 >= p.C) continue;
-        float w[8][C0_MAXK], acc[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8], m1[8], m2[8], accb[8];
+    float w[8][C0_MAXK], acc[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8], m1[8], m2[8], accb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f; m1[j] = m2[j] = 0.f; accb[j] = 0.f; cb[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C0_MAXK; ++t) { acc[j][t] = 0.f; w[j][t] = 0.f; }
+    }
+    if (c0 < p.C) {
         load_w8(p, c0, w, cb);
+        if (p.group) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f; m1[j] = m2[j] = 0.f; accb[j] = 0.f;
-#pragma unroll
-            for (int t = 0; t < C0_MAXK; ++t) acc[j][t] = 0.f;
-            if (p.group) {
+            for (int j = 0; j < 8; ++j) {
                 mean_rstd(p, b, c0 + j, mu[j], rs[j]);
                 gm[j] = p.gamma[c0 + j]; bt[j] = p.beta[c0 + j];
                 m1[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2] * invT);
                 m2[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2 + 1] * invT);
             }
         }
-        for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
-            const float* x = sx + tt * p.stride;
-            float d[8];
-            load8(dY + (long long)(t0 + tt) * p.C + c0, d);
+    }
+    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
+        const int t0 = tile * C0_TT;
+        __syncthreads();
+        stage_wave(p, sx, b, t0);
+        __syncthreads();
+        if (c0 < p.C) {
+            for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
+                const float* x = sx + tt * p.stride;
+                float d[8];
+                load8(dY + (long long)(t0 + tt) * p.C + c0, d);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float du = d[j];
-                if (p.group) {
-                    float u = cb[j];
+                for (int j = 0; j < 8; ++j) {
+                    float du = d[j];
+                    if (p.group) {
+                        float u = cb[j];
 #pragma unroll
-                    for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
-                    const float xh = (u - mu[j]) * rs[j];
-                    const float dz = du * act_grad(xh * gm[j] + bt[j], SMX_ACT_GELU);
-                    du = gm[j] * rs[j] * (dz - m1[j] - xh * m2[j]);
+                        for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
+                        const float xh = (u - mu[j]) * rs[j];
+                        const float dz = du * act_grad(xh * gm[j] + bt[j], SMX_ACT_GELU);
+                        du = gm[j] * rs[j] * (dz - m1[j] - xh * m2[j]);
+                    }
+                    accb[j] += du;
+#pragma unroll
+                    for (int t = 0; t < C0_MAXK; ++t) acc[j][t] = fmaf(du, x[t], acc[j][t]);
                 }
-                accb[j] += du;
-#pragma unroll
-                for (int t = 0; t < C0_MAXK; ++t) acc[j][t] = fmaf(du, x[t], acc[j][t]);
             }
         }
+    }
+    // reduce the 4 waves (same channels, different time steps), one tap at a time
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+    for (int t = 0; t <= C0_MAXK; ++t) {
+        if (t < C0_MAXK && t >= p.k) continue;
+        __syncthreads();
 #pragma unroll
-            for (int t = 0; t < C0_MAXK; ++t)
-                if (t < p.k) atomicAdd(p.dw + (c0 + j) * p.k + t, acc[j][t]);
-            if (p.dcbias && !p.group) atomicAdd(p.dcbias + c0 + j, accb[j]);
+        for (int j = 0; j < 8; ++j) red[wv][lane][j] = t < C0_MAXK ? acc[j][t] : accb[j];
+        __syncthreads();
+        if (wv == 0 && c0 < p.C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
+                if (t < C0_MAXK) atomicAdd(p.dw + (c0 + j) * p.k + t, v);
+                else if (p.dcbias && !p.group) atomicAdd(p.dcbias + c0 + j, v);
+            }
         }
     }
 }
 
 static int conv0_check(const SmxConv0Params& p) {
-    if (p.B <= 0 || p.C <= 0 || (p.C & 7) || p.k > C0_MAXK || p.k <= 0 || p.stride <= 0 || p.stride > 8) return SMX_EINVAL;
+    if (p.B <= 0 || p.C <= 0 || (p.C & 7) || p.C > 512 || p.k > C0_MAXK || p.k <= 0 || p.stride <= 0 || p.stride > 8) return SMX_EINVAL;
     if (p.T0 != (p.N - p.k) / p.stride + 1 || p.T0 <= 0) return SMX_EINVAL;
     return SMX_OK;
 }
@@ -277,11 +305,14 @@ extern "C" int smx_conv0_fwd(const SmxConv0Params* pp, int dtype, hipStream_t st
     SmxConv0Params p = *pp;
     int rc = conv0_check(p);
     if (rc) return rc;
-    dim3 grid((p.T0 + C0_TT - 1) / C0_TT, p.B);
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    dim3 grid(ntiles, p.B);
+    p.tiles_per_block = max(1, (ntiles * p.B + 1023) / 1024);
+    dim3 rgrid((ntiles + p.tiles_per_block - 1) / p.tiles_per_block, p.B);
     if (p.group) {
         if (!p.stats || !p.gamma || !p.beta) return SMX_EINVAL;
         hipMemsetAsync(p.stats, 0, sizeof(double) * 2 * p.B * p.C, stream);
-        hipLaunchKernelGGL(conv0_stats_kernel, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(conv0_stats_kernel, rgrid, dim3(256), 0, stream, p);
     }
     if (dtype == SMX_F32) hipLaunchKernelGGL(conv0_apply_kernel<float>, grid, dim3(256), 0, stream, p);
     else if (dtype == SMX_BF16) hipLaunchKernelGGL(conv0_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
@@ -296,7 +327,9 @@ extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t st
     int rc = conv0_check(p);
     if (rc) return rc;
     if (dtype != SMX_F32 && dtype != SMX_BF16) return SMX_EINVAL;
-    dim3 grid((p.T0 + C0_TT - 1) / C0_TT, p.B);
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    p.tiles_per_block = max(1, (ntiles * p.B + 1023) / 1024);
+    dim3 grid((ntiles + p.tiles_per_block - 1) / p.tiles_per_block, p.B);
     if (p.group) {
         if (!p.stats || !p.bstats) return SMX_EINVAL;
         hipMemsetAsync(p.bstats, 0, sizeof(double) * 2 * p.B * p.C, stream);

@@ -144,15 +144,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     const int c = (blockIdx.x * 64 + lane) * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c < N) {
-        for (int m = blockIdx.y * 4 + w; m < M; m += gridDim.y * 4) {
-            float v[8];
-            if (c + 8 <= N) load8(x + (long long)m * ld + c, v);
-            else {
+        const int step = gridDim.y * 4;
+        if (c + 8 <= N) {
+            int m = blockIdx.y * 4 + w;
+            for (; m + 3 * step < M; m += 4 * step) {      // 4 independent 16-B loads in flight per lane
+                float v0[8], v1[8], v2[8], v3[8];
+                load8(x + (long long)m * ld + c, v0);
+                load8(x + (long long)(m + step) * ld + c, v1);
+                load8(x + (long long)(m + 2 * step) * ld + c, v2);
+                load8(x + (long long)(m + 3 * step) * ld + c, v3);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = c + e < N ? Cvt<T>::ld(x + (long long)m * ld + c + e) : 0.f;
+                for (int e = 0; e < 8; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
             }
+            for (; m < M; m += step) {
+                float v[8];
+                load8(x + (long long)m * ld + c, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+        } else {
+            for (int m = blockIdx.y * 4 + w; m < M; m += step) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += c + e < N ? Cvt<T>::ld(x + (long long)m * ld + c + e) : 0.f;
+            }
         }
     }
 #pragma unroll
@@ -167,9 +181,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (M <= 0 || N <= 0 || (ld & 7)) return SMX_EINVAL;
-    int gy = (M + 63) / 64;
-    if (gy > 64) gy = 64;
-    dim3 grid((N + 511) / 512, gy);
+    const int gx = (N + 511) / 512;
+    int gy = (M + 31) / 32;
+    const int cap = max(1, 1024 / gx);
+    if (gy > cap) gy = cap;
+    dim3 grid(gx, gy);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, M, N, ld, alpha);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, M, N, ld, alpha);
     else return SMX_EINVAL;

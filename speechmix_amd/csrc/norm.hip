@@ -107,98 +107,159 @@ struct SmxNormBwdParams {
     float* dgamma;        // [D] fp32, accumulated atomically (or null)
     float* dbeta;         // [D] or null
     float* dpos;          // optional fp32 [*, D]: positional table gradient (atomic), same indexing as fwd
+    float* partials;      // workspace [ceil(M/16)][2][D] fp32: per-block column sums, reduced by a 2nd kernel
     int M, D;
     int pos_period, pos_offset;
     int rms, act;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(SmxNormBwdParams p) {
+// Backward is two kernels: (1) dx, one wave per row at full occupancy (like the forward); (2) the gamma/beta
+// gradients as per-block column partial sums over row chunks (no shuffles, no stores in the row loop),
+// finished by a tiny column reduction.  Splitting costs one extra read of (x, dy) but removes the long-lived
+// 32-register column accumulators from the latency-critical dx path.
+template <typename T, bool ACT>
+__global__ __launch_bounds__(256) void norm_bwd_dx_kernel(SmxNormBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const T* x = reinterpret_cast<const T*>(p.x) + (long long)row * p.D;
+    const T* dy = reinterpret_cast<const T*>(p.dy) + (long long)row * p.D;
+    const float mean = p.rms ? 0.f : p.mean[row];
+    const float rstd = p.rstd[row];
+    const float invD = 1.0f / (float)p.D;
+    float xh[LN_NCH][8], g[LN_NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < p.D) {
+            float xv[8], dv[8], gm[8], bt[8];
+            load8(x + c, xv);
+            load8(dy + c, dv);
+            load8(p.gamma + c, gm);
+            if (ACT) {
+                if (p.beta) load8(p.beta + c, bt);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bt[e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xhat = (xv[e] - mean) * rstd;
+                float d = dv[e];
+                if (ACT) d *= act_grad(xhat * gm[e] + bt[e], p.act);
+                const float gg = d * gm[e];
+                xh[j][e] = xhat;
+                g[j][e] = gg;
+                s1 += gg;
+                s2 += gg * xhat;
+            }
+        }
+    }
+    s1 = p.rms ? 0.f : wave_sum(s1) * invD;
+    s2 = wave_sum(s2) * invD;
+    T* dx = reinterpret_cast<T*>(p.dx) + (long long)row * p.D;
+    const T* dres = p.dres ? reinterpret_cast<const T*>(p.dres) + (long long)row * p.D : nullptr;
+    float* dpos = p.dpos ? p.dpos + (long long)((row % p.pos_period) + p.pos_offset) * p.D : nullptr;
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < p.D) {
+            float o[8], r[8];
+            if (dres) load8(dres + c, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (g[j][e] - s1 - xh[j][e] * s2) * rstd;
+                if (dpos) atomicAdd(dpos + c + e, o[e]);
+                if (dres) o[e] += r[e];
+            }
+            store8(dx + c, o);
+        }
+    }
+}
+
+#define LN_PR 4   // rows per wave in the parameter-gradient kernel (all their loads are issued up front)
+template <typename T, bool ACT>
+__global__ __launch_bounds__(256) void norm_bwd_param_kernel(SmxNormBwdParams p) {
     __shared__ float red[4][64][8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nwaves = gridDim.x * 4;
+    const int row0 = (blockIdx.x * 4 + w) * LN_PR;
     float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
 #pragma unroll
     for (int j = 0; j < LN_NCH; ++j) {
         const int c = (lane + 64 * j) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dg[j][e] = db[j][e] = gm[j][e] = bt[j][e] = 0.f;
-        if (c < p.D) {
+        if (ACT && c < p.D) {
             load8(p.gamma + c, gm[j]);
-            if (p.beta && p.act != SMX_ACT_NONE) load8(p.beta + c, bt[j]);
+            if (p.beta) load8(p.beta + c, bt[j]);
         }
     }
-    const float invD = 1.0f / (float)p.D;
-    for (int row = blockIdx.x * 4 + w; row < p.M; row += nwaves) {
-        const T* x = reinterpret_cast<const T*>(p.x) + (long long)row * p.D;
-        const T* dy = reinterpret_cast<const T*>(p.dy) + (long long)row * p.D;
-        const float mean = p.rms ? 0.f : p.mean[row];
-        const float rstd = p.rstd[row];
-        float xh[LN_NCH][8], g[LN_NCH][8];
-        float s1 = 0.f, s2 = 0.f;
+    float xv[LN_PR][LN_NCH][8], dv[LN_PR][LN_NCH][8], mean[LN_PR], rstd[LN_PR];
+#pragma unroll
+    for (int r = 0; r < LN_PR; ++r) {
+        const int row = row0 + r;
+        mean[r] = 0.f; rstd[r] = 0.f;
+        if (row < p.M) {
+            mean[r] = p.rms ? 0.f : p.mean[row];
+            rstd[r] = p.rstd[row];
+        }
 #pragma unroll
         for (int j = 0; j < LN_NCH; ++j) {
             const int c = (lane + 64 * j) * 8;
-            if (c < p.D) {
-                float xv[8], dv[8];
-                load8(x + c, xv);
-                load8(dy + c, dv);
+            if (row < p.M && c < p.D) {
+                load8(reinterpret_cast<const T*>(p.x) + (long long)row * p.D + c, xv[r][j]);
+                load8(reinterpret_cast<const T*>(p.dy) + (long long)row * p.D + c, dv[r][j]);
+            } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float xhat = (xv[e] - mean) * rstd;
-                    float d = dv[e];
-                    if (p.act != SMX_ACT_NONE) d *= act_grad(xhat * gm[j][e] + bt[j][e], p.act);
-                    dg[j][e] += d * xhat;
-                    db[j][e] += d;
-                    const float gg = d * gm[j][e];
-                    xh[j][e] = xhat;
-                    g[j][e] = gg;
-                    s1 += gg;
-                    s2 += gg * xhat;
-                }
-            }
-        }
-        s1 = p.rms ? 0.f : wave_sum(s1) * invD;
-        s2 = wave_sum(s2) * invD;
-        T* dx = reinterpret_cast<T*>(p.dx) + (long long)row * p.D;
-        const T* dres = p.dres ? reinterpret_cast<const T*>(p.dres) + (long long)row * p.D : nullptr;
-        float* dpos = p.dpos ? p.dpos + (long long)((row % p.pos_period) + p.pos_offset) * p.D : nullptr;
-#pragma unroll
-        for (int j = 0; j < LN_NCH; ++j) {
-            const int c = (lane + 64 * j) * 8;
-            if (c < p.D) {
-                float o[8], r[8];
-                if (dres) load8(dres + c, r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    o[e] = (g[j][e] - s1 - xh[j][e] * s2) * rstd;
-                    if (dpos) atomicAdd(dpos + c + e, o[e]);
-                    if (dres) o[e] += r[e];
-                }
-                store8(dx + c, o);
+                for (int e = 0; e < 8; ++e) xv[r][j][e] = dv[r][j][e] = 0.f;
             }
         }
     }
-    if (!p.dgamma && !p.dbeta) return;
-    // block reduction of the per-wave column partials, then one atomic per column per block
+#pragma unroll
+    for (int r = 0; r < LN_PR; ++r)
+#pragma unroll
+        for (int j = 0; j < LN_NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xhat = (xv[r][j][e] - mean[r]) * rstd[r];
+                float d = dv[r][j][e];
+                if (ACT) d *= act_grad(xhat * gm[j][e] + bt[j][e], p.act);
+                dg[j][e] += d * xhat;
+                db[j][e] += d;
+            }
 #pragma unroll
     for (int j = 0; j < LN_NCH; ++j) {
         if (64 * 8 * j >= p.D) break;
         const int c = (lane + 64 * j) * 8;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            float* dst = pass == 0 ? p.dgamma : p.dbeta;
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[w][lane][e] = pass == 0 ? dg[j][e] : db[j][e];
             __syncthreads();
-            if (w == 0 && c < p.D && dst) {
+            if (w == 0 && c < p.D) {
+                float sum8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    atomicAdd(dst + c + e, red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e]);
+                for (int e = 0; e < 8; ++e) sum8[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+                store8(p.partials + ((long long)blockIdx.x * 2 + pass) * p.D + c, sum8);
             }
         }
     }
+}
+
+// second stage of the gamma/beta gradient: column sums over the per-block partials (grid.y-way split rows)
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int D, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float g = 0.f, b = 0.f;
+    for (int i = blockIdx.y; i < nblocks; i += gridDim.y) {
+        g += partials[((long long)i * 2) * D + c];
+        b += partials[((long long)i * 2 + 1) * D + c];
+    }
+    if (dgamma) atomicAdd(dgamma + c, g);
+    if (dbeta) atomicAdd(dbeta + c, b);
 }
 
 extern "C" int smx_norm_fwd(const SmxNormParams* pp, int dtype, hipStream_t stream) {
@@ -218,11 +279,29 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     SmxNormBwdParams p = *pp;
     if (p.M <= 0 || p.D <= 0 || p.D > 64 * 8 * LN_NCH || (p.D & 7)) return SMX_EINVAL;
     if (p.dpos && p.pos_period <= 0) return SMX_EINVAL;
-    int blocks = (p.M + 3) / 4;
-    if (blocks > 512) blocks = 512;
-    if (dtype == SMX_F32) hipLaunchKernelGGL(norm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
-    else if (dtype == SMX_BF16) hipLaunchKernelGGL(norm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
-    else return SMX_EINVAL;
+    if (dtype != SMX_F32 && dtype != SMX_BF16) return SMX_EINVAL;
+    if ((p.dgamma || p.dbeta) && !p.partials) return SMX_EINVAL;
+    const bool act = p.act != SMX_ACT_NONE;
+    dim3 grid((p.M + 3) / 4);
+    if (dtype == SMX_F32) {
+        if (act) hipLaunchKernelGGL((norm_bwd_dx_kernel<float, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((norm_bwd_dx_kernel<float, false>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (act) hipLaunchKernelGGL((norm_bwd_dx_kernel<bf16_t, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((norm_bwd_dx_kernel<bf16_t, false>), grid, dim3(256), 0, stream, p);
+    }
+    if (p.dgamma || p.dbeta) {
+        const int blocks = (p.M + 4 * LN_PR - 1) / (4 * LN_PR);   // workspace: blocks * 2 * D floats
+        if (dtype == SMX_F32) {
+            if (act) hipLaunchKernelGGL((norm_bwd_param_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((norm_bwd_param_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, p);
+        } else {
+            if (act) hipLaunchKernelGGL((norm_bwd_param_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((norm_bwd_param_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
+        }
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((p.D + 63) / 64, blocks >= 64 ? 32 : 1), dim3(64), 0, stream,
+                           p.partials, blocks, p.D, p.dgamma, p.dbeta);
+    }
     SMX_CHECK_LAUNCH();
 }
 

@@ -106,9 +106,18 @@ def norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dtype, eps=1e-5, rms=False, ac
 
 def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms=False, act=ACT_NONE, dres=None,
              dpos=None, pos_period=0, pos_offset=0):
+    ws = None
+    if dgamma is not None or dbeta is not None:
+        need = ((M + 15) // 16) * 2 * D
+        ws = _NORM_WS.get(dy.device)
+        if ws is None or ws.numel() < need:
+            ws = _NORM_WS[dy.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=dy.device)
     p = L.NormBwdParams(_ptr(dy), _ptr(x), _ptr(dres), _ptr(dx), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
-                        _ptr(dgamma), _ptr(dbeta), _ptr(dpos), M, D, pos_period, pos_offset, int(rms), act)
+                        _ptr(dgamma), _ptr(dbeta), _ptr(dpos), _ptr(ws), M, D, pos_period, pos_offset, int(rms), act)
     L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
+
+
+_NORM_WS = {}
 
 
 class AttnDesc:

@@ -46,7 +46,7 @@ def norm_case(dtype, tdt, tol, M, D, rms, act, with_pos):
     dpos = torch.zeros(S + 2, D, device=dev) if with_pos else None
     dyd = dy.to(dev); dresd = dres.to(dev)
     pb = L.NormBwdParams(ptr(dyd), ptr(xs if with_pos else xd), ptr(dresd), ptr(dx), ptr(gd), ptr(bd), ptr(mean), ptr(rstd),
-                         ptr(dg), ptr(db) if not rms else None, ptr(dpos), M, D, S, 2, rms, act)
+                         ptr(dg), ptr(db) if not rms else None, ptr(dpos), ptr(torch.empty(4 << 20, device=dev)), M, D, S, 2, rms, act)
     assert lib.smx_norm_bwd(C.byref(pb), dtype, stream()) == 0
     ok &= check(nm + " dx", dx, xr.grad + dres.float(), tol * 4)
     ok &= check(nm + " dgamma", dg, gr.grad, tol * 4)
@@ -128,8 +128,9 @@ def main():
     M, D = 15968, 768
     x = torch.randn(M, D, device=dev).bfloat16(); y = torch.empty_like(x); g = torch.ones(D, device=dev); b = torch.zeros(D, device=dev)
     mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev); dx = torch.empty_like(x); dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+    ws = torch.empty(4 << 20, device=dev)
     pn = L.NormParams(ptr(x), None, None, ptr(y), ptr(g), ptr(b), ptr(mean), ptr(rstd), M, D, 0, 0, 0, 0, 1e-5)
-    pb = L.NormBwdParams(ptr(y), ptr(x), None, ptr(dx), ptr(g), ptr(b), ptr(mean), ptr(rstd), ptr(dg), ptr(db), None, M, D, 0, 0, 0, 0)
+    pb = L.NormBwdParams(ptr(y), ptr(x), None, ptr(dx), ptr(g), ptr(b), ptr(mean), ptr(rstd), ptr(dg), ptr(db), None, ptr(ws), M, D, 0, 0, 0, 0)
     for name, fn, byts in (("ln fwd 15968x768", lambda: lib.smx_norm_fwd(C.byref(pn), L.BF16, stream()), 2 * M * D * 2),
                            ("ln bwd 15968x768", lambda: lib.smx_norm_bwd(C.byref(pb), L.BF16, stream()), 3 * M * D * 2)):
         for _ in range(200): fn()
