@@ -28,7 +28,8 @@ class GemmParams(C.Structure):
                 ("batch_bias", C.c_longlong), ("batch_e", C.c_longlong),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_rc", C.c_int), ("b_rc", C.c_int),
                 ("act", C.c_int), ("out_f32", C.c_int), ("atomic", C.c_int), ("nbatch", C.c_int),
-                ("split_k", C.c_int), ("tr_mode", C.c_int), ("alpha", C.c_float)]
+                ("split_k", C.c_int), ("tr_mode", C.c_int), ("alpha", C.c_float),
+                ("split_stride", C.c_longlong)]
 
 
 _lib = None

@@ -32,10 +32,11 @@ struct SmxGemmParams {
     int a_rc, b_rc;
     int act;                // SMX_ACT_* applied after bias (fwd) or used for aux_in derivative
     int out_f32;            // C is fp32 regardless of input dtype
-    int atomic;             // C += via fp32 atomics (requires out_f32)
-    int nbatch, split_k;
-    int tr_mode;            // 1: ds_read_b64_tr_b16 for RC operands, 0: 16-bit LDS reads (debug/fallback)
+    int atomic;             // 0: C = .., 1: C += via fp32 atomics, 2: C += by plain read-modify-write (split_k == 1)
+    int nbatch, split_k;    // split_k > 1 with atomic == 0: split s writes its partial to C + s * split_stride ("slabs")
+    int tr_mode;            // 1: LDS-DMA kernel (production), 2: register-staged + tr reads, 0: 16-bit LDS reads (debug)
     float alpha;
+    long long split_stride; // elements between split-K slabs (atomic == 0)
 };
 
 #define BM 128
@@ -155,10 +156,22 @@ __device__ __forceinline__ void epilogue4(const SmxGemmParams& p, long long zc, 
     }
     if (p.out_f32) {
         float* c = reinterpret_cast<float*>(p.C) + base;
-        if (p.atomic) {
+        if (p.atomic == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (j < nv) atomicAdd(c + j, v[j]);
+        } else if (p.atomic == 2) {
+            if (nv == 4 && ((base & 3) == 0)) {
+                float4 o = *reinterpret_cast<float4*>(c);
+                o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                *reinterpret_cast<float4*>(c) = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nv) c[j] += v[j];
+            }
+        } else if (nv == 4 && ((base & 3) == 0)) {
+            *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -199,13 +212,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
     const int zb = z / p.split_k, zs = z - zb * p.split_k;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
-    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
+    const long long zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
 
     // K range of this split (multiple of BK)
     const int ksteps_total = (p.K + BK - 1) / BK;
     const int per = (ksteps_total + p.split_k - 1) / p.split_k;
     const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
-    if (ks0 >= ks1 && p.split_k > 1) return;
+    if (ks0 >= ks1 && p.split_k > 1 && p.atomic == 1) return;
 
     TileLoader<A_RC> la;
     TileLoader<B_RC> lb;
@@ -266,6 +279,153 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16, direct-to-LDS variant (the production path): the same 128x128x64 tiling and LDS images, but tiles are
+// filled with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass).  An LDS-DMA writes
+// wave-uniform-base + lane*16, so the LDS image stays lane-linear and the XOR swizzles are applied to the
+// per-lane SOURCE address instead (same involution on the read side).  Out-of-range rows / k read a 64-B
+// zero page through the per-lane source pointer.  One 32-KB LDS buffer and <=128 registers per lane:
+// 4 workgroups per CU hide each other's fill latency (two barriers per K step).
+// ------------------------------------------------------------------------------------------------
+__device__ uint4 smx_zero_page[4];
+
+typedef __attribute__((address_space(3))) void* lds_vp_t;
+typedef const __attribute__((address_space(1))) void* glb_vp_t;
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_vp_t)src, (lds_vp_t)lds_wave_base, 16, 0, 0);
+}
+
+template <bool RC>
+struct DmaLoader {
+    const bf16_t* ptr[4];    // KC: current source pointer of my 4 chunks (or the zero page)
+    int inc[4];              // KC: elements to advance per K step (0 for the zero page)
+    int kc;                  // KC: my k offset inside a step (source chunk * 8)
+    // RC state: per-pass (batch, row-in-batch) of the k-row, advanced incrementally
+    int rb[4], rt[4];
+    int col;                 // RC: my source column (elements), < 0: out of range
+    const bf16_t* base;
+    const bf16_t* zero;
+
+    __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& v, int row0, int nrows, int k0, int tid) {
+        base = b;
+        zero = reinterpret_cast<const bf16_t*>(smx_zero_page);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (!RC) {
+            kc = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int rl = p * 32 + wave * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((rl >> 1) & 7);
+                if (p == 0) kc = c * 8;       // identical for all p: (rl>>1)&7 only depends on wave*8+(lane>>3)
+                const bool ok = row0 + rl < nrows;
+                ptr[p] = ok ? b + view_off(v, row0 + rl) + c * 8 + k0 : zero;
+                inc[p] = ok ? BK : 0;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = k0 + p * 16 + wave * 4 + (lane >> 4);
+                if (v.rows_per_batch > 0) { rb[p] = k / v.rows_per_batch; rt[p] = k - rb[p] * v.rows_per_batch; }
+                else { rb[p] = 0; rt[p] = k; }
+            }
+            col = -1;   // set per call (depends on the k-row swizzle): see issue()
+        }
+    }
+    __device__ __forceinline__ void issue(char* tile, const SmxRowView& v, int row0, int nrows, int k0, int K, int tid) {
+        const int lane = tid & 63, wave = tid >> 6;
+        if (!RC) {
+            const bool kin = k0 + kc < K;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                glds16(kin ? ptr[p] : zero, tile + (p * 32 + wave * 8) * 128);
+                ptr[p] += inc[p];
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int kl = p * 16 + wave * 4 + (lane >> 4);
+                const int g16 = lane & 15;
+                const int c = row0 + ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
+                const bf16_t* src = zero;
+                if (k0 + kl < K && c < nrows)
+                    src = base + v.off + (long long)rb[p] * v.batch_stride + (long long)rt[p] * v.ld + c;
+                glds16(src, tile + (p * 16 + wave * 4) * 256);
+                rt[p] += BK;
+                if (v.rows_per_batch > 0) {
+                    while (rt[p] >= v.rows_per_batch) { rt[p] -= v.rows_per_batch; rb[p] += 1; }
+                }
+            }
+        }
+    }
+};
+
+template <bool A_RC, bool B_RC>
+__global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int tm = wg / ntn, tn = wg - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const int zb = z / p.split_k, zs = z - zb * p.split_k;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
+    const long long zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
+    const int ksteps_total = (p.K + BK - 1) / BK;
+    const int per = (ksteps_total + p.split_k - 1) / p.split_k;
+    const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
+    if (ks0 >= ks1 && p.split_k > 1 && p.atomic == 1) return;
+
+    DmaLoader<A_RC> la;
+    DmaLoader<B_RC> lb;
+    la.init(A, p.a, m0, p.M, ks0 * BK, tid);
+    lb.init(B, p.b, n0, p.N, ks0 * BK, tid);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    char* tA = smem;
+    char* tB = smem + 16384;
+    for (int ks = ks0; ks < ks1; ++ks) {
+        la.issue(tA, p.a, m0, p.M, ks * BK, p.K, tid);
+        lb.issue(tB, p.b, n0, p.N, ks * BK, p.K, tid);
+        __syncthreads();                 // (the compiler drains the LDS-DMA queue before the barrier)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_RC>(tA, wm * 64 + i * 16, kk, lane, 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_RC>(tB, wn * 64 + j * 16, kk, lane, 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                 // everyone is done reading before the next fill overwrites the tile
+    }
+    const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            epilogue4<bf16_t>(p, zc, zbias, ze, m0 + wm * 64 + i * 16 + i16, n0 + wn * 64 + j * 16 + 4 * g, v);
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp32: simple 64x64x16 VALU tile kernel with fully generic operand addressing.
 // ------------------------------------------------------------------------------------------------
@@ -280,11 +440,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
     const int zb = z / p.split_k, zs = z - zb * p.split_k;
     const float* A = reinterpret_cast<const float*>(p.A) + (long long)zb * p.batch_a;
     const float* B = reinterpret_cast<const float*>(p.B) + (long long)zb * p.batch_b;
-    const long long zc = (long long)zb * p.batch_c, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
+    const long long zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride, zbias = (long long)zb * p.batch_bias, ze = (long long)zb * p.batch_e;
     const int ksteps_total = (p.K + 15) / 16;
     const int per = (ksteps_total + p.split_k - 1) / p.split_k;
     const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
-    if (ks0 >= ks1 && p.split_k > 1) return;
+    if (ks0 >= ks1 && p.split_k > 1 && p.atomic == 1) return;
 
     const int tx = tid & 15, ty = tid >> 4;  // each thread: 4 m (ty*4..) x 4 n (tx*4..)
     float acc[4][4] = {};
@@ -343,9 +503,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
             else x *= act_grad(reinterpret_cast<const float*>(p.aux_in)[rowe + n], p.act);
             if (p.resid) x += reinterpret_cast<const float*>(p.resid)[rowe + n];
             float* c = reinterpret_cast<float*>(p.C) + rowb + n;
-            if (p.atomic) atomicAdd(c, x); else *c = x;
+            if (p.atomic == 1) atomicAdd(c, x); else if (p.atomic == 2) *c += x; else *c = x;
         }
     }
+}
+
+// dst[i] (+)= sum_s slabs[s * stride + i]   (second stage of the split-K weight gradients)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long long n, long long stride,
+                                    float* __restrict__ dst, int accumulate) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (; i + 4 <= n; i += step) {
+        float4 a = accumulate ? *reinterpret_cast<const float4*>(dst + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < nsplit; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + s * stride + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + i) = a;
+    }
+}
+extern "C" int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stride, float* dst, int accumulate,
+                                hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0 || (n & 3) || (stride & 3) || nsplit < 1) return SMX_EINVAL;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, slabs, nsplit, n, stride, dst, accumulate);
+    SMX_CHECK_LAUNCH();
 }
 
 extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) {
@@ -354,7 +538,7 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     if (p.M <= 0 || p.N <= 0 || p.K < 0) return SMX_EINVAL;
     if (p.nbatch < 1) p.nbatch = 1;
     if (p.split_k < 1) p.split_k = 1;
-    if (p.split_k > 1 && !p.atomic) return SMX_EINVAL;
+    if (p.split_k > 1 && p.atomic != 1 && (p.atomic == 2 || p.split_stride <= 0)) return SMX_EINVAL;
     if (p.atomic && !(p.out_f32 || dtype == SMX_F32)) return SMX_EINVAL;
     if (dtype == SMX_F32) {
         p.out_f32 = 1;
@@ -364,6 +548,19 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     }
     if (dtype != SMX_BF16) return SMX_EINVAL;
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
+    if (p.tr_mode == 1) {   // production path: LDS-DMA fills
+        const size_t ldsz = STAGE_BYTES;
+        if (!p.a_rc && !p.b_rc)
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false>), grid, dim3(256), ldsz, stream, p);
+        else if (!p.a_rc && p.b_rc)
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, true>), grid, dim3(256), ldsz, stream, p);
+        else if (p.a_rc && !p.b_rc)
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, false>), grid, dim3(256), ldsz, stream, p);
+        else
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, true>), grid, dim3(256), ldsz, stream, p);
+        SMX_CHECK_LAUNCH();
+    }
+    if (p.tr_mode == 2) p.tr_mode = 1;   // register-staged kernel with transposing reads
     const size_t lds = 2 * STAGE_BYTES;
     if (!p.a_rc && !p.b_rc)
         hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), lds, stream, p);

@@ -182,8 +182,8 @@ extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld,
     (void)hipGetLastError();  // drop stale errors left by other runtime users
     if (M <= 0 || N <= 0 || (ld & 7)) return SMX_EINVAL;
     const int gx = (N + 511) / 512;
-    int gy = (M + 31) / 32;
-    const int cap = max(1, 1024 / gx);
+    int gy = (M + 63) / 64;      // few blocks per column strip: the final fp32 atomics serialise in L2
+    const int cap = max(1, 128 / gx);
     if (gy > cap) gy = cap;
     dim3 grid(gx, gy);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, out, M, N, ld, alpha);

@@ -71,14 +71,26 @@ __device__ __forceinline__ float rt(float v, const float*) { return v; }
 
 // ---- activations (exact erf GELU as in HF ACT2FN["gelu"]) ----
 enum { SMX_ACT_NONE = 0, SMX_ACT_GELU = 1, SMX_ACT_RELU = 2 };
+// erf for the GELU epilogues: branch-free Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off
+// class) - libm's erff is a divergent piecewise evaluation that made the FFN1 epilogue cost more than its GEMM.
+__device__ __forceinline__ float smx_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float r = 1.0f - poly * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
 __device__ __forceinline__ float act_fwd(float x, int act) {
-    if (act == SMX_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (act == SMX_ACT_GELU) return 0.5f * x * (1.0f + smx_erf(x * 0.70710678118654752440f));
     if (act == SMX_ACT_RELU) return x > 0.f ? x : 0.f;
     return x;
 }
 __device__ __forceinline__ float act_grad(float x, int act) {
     if (act == SMX_ACT_GELU) {
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float cdf = 0.5f * (1.0f + smx_erf(x * 0.70710678118654752440f));
         const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
         return cdf + x * pdf;
     }

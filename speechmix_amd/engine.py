@@ -67,6 +67,14 @@ class Engine:
             self._persist[key] = t
         return t
 
+    def workspace(self, key, numel, dt):
+        """Grow-only scratch buffer that lives across steps (contents undefined)."""
+        t = self._persist.get(key)
+        if t is None or t.numel() < numel or t.dtype != dt:
+            t = torch.empty(max(numel, 1), dtype=dt, device=self.dev)
+            self._persist[key] = t
+        return t
+
     def W(self, n): return self.st.w(n)
     def P(self, n): return self.st.p32(n)
     def G(self, n): return self.st.g(n)
@@ -76,7 +84,11 @@ class Engine:
     def _split(self, Mo, No, Kred):
         tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
         ksteps = (Kred + 63) // 64
-        return int(max(1, min(512 // max(tiles, 1), ksteps // 8, 32)))
+        # 4 workgroups/CU x 256 CUs are resident at once: aim for ~1 full wave of workgroups, keep every split
+        # non-empty and at least 8 K-steps long (slab traffic grows with the split count)
+        want = int(max(1, min((1024 + tiles - 1) // max(tiles, 1), ksteps // 8, 32)))
+        per = (ksteps + want - 1) // want
+        return (ksteps + per - 1) // per
 
     # ------------------------------------------------------------------ linear building blocks
     def lin(self, x, w, b, M, N, K, y=None, act=ACT_NONE, resid=None, aux_out=None, av=None, cv=None, ev=None,
@@ -95,10 +107,21 @@ class Engine:
         return dx
 
     def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, **kw):
-        """gw[N,K] += dy[M,N]^T @ x[M,K]  (fp32 atomics, split over M);  gb[N] += colsum(dy)."""
-        ops.gemm(dy, x, gw, N, K, M, self.dt, a_rc=True, b_rc=True, av=dyv if dyv is not None else view(N),
-                 bv=xv if xv is not None else view(K), out_f32=True, atomic=True, split_k=self._split(N, K, M),
-                 alpha=alpha, **kw)
+        """gw[N,K] += dy[M,N]^T @ x[M,K];  gb[N] += colsum(dy).  The reduction over M is split across workgroups
+        when the output has too few tiles to fill the chip: each split stores its fp32 partial slab and one
+        streaming pass sums the slabs into the gradient (no atomics: they serialise in L2)."""
+        split = self._split(N, K, M)
+        av = dyv if dyv is not None else view(N)
+        bv = xv if xv is not None else view(K)
+        if split <= 1:
+            ops.gemm(dy, x, gw, N, K, M, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, out_f32=True, atomic=2, alpha=alpha,
+                     **kw)
+        else:
+            n = N * K
+            slabs = self.workspace("wgrad_slabs", split * n, torch.float32)
+            ops.gemm(dy, x, slabs, N, K, M, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, out_f32=True, atomic=0,
+                     split_k=split, split_stride=n, alpha=alpha, **kw)
+            ops.reduce_slabs(slabs, split, n, n, gw, accumulate=True)
         if gb is not None:
             ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha)
 
@@ -486,11 +509,14 @@ class Engine:
         v_n, g_n = pre_n + "parametrizations.weight.original1", pre_n + "parametrizations.weight.original0"
         if self.tr(v_n, g_n, pre_n + "bias"):
             ops.colsum(dpre, self.G(pre_n + "bias"), B * T, d, d, self.dt)
-            dwp = self.zeros(G * Cg * K * Cg, dt=torch.float32)
-            ops.gemm(dpre, sv["xg"], dwp, Cg, K * Cg, B * T, self.dt, a_rc=True, b_rc=True, av=view(d),
-                     bv=view(Cg, T, Tp * Cg), cv=view(K * Cg), out_f32=True, atomic=True,
-                     split_k=self._split(Cg, K * Cg, B * T), nbatch=G, batch_a=Cg, batch_b=B * Tp * Cg,
-                     batch_c=Cg * K * Cg)
+            n = G * Cg * K * Cg
+            dwp = self.new(n, dt=torch.float32)
+            split = self._split(Cg, K * Cg * G, B * T)
+            slabs = self.workspace("wgrad_slabs", split * n, torch.float32)
+            ops.gemm(dpre, sv["xg"], slabs, Cg, K * Cg, B * T, self.dt, a_rc=True, b_rc=True, av=view(d),
+                     bv=view(Cg, T, Tp * Cg), cv=view(K * Cg), out_f32=True, atomic=0, split_k=split, split_stride=n,
+                     nbatch=G, batch_a=Cg, batch_b=B * Tp * Cg, batch_c=Cg * K * Cg)
+            ops.reduce_slabs(slabs, split, n, n, dwp, accumulate=False)
             scratch = self.new(K, dt=torch.float32)
             ops.wn_bwd(dwp, self.P(v_n), self.P(g_n), sv["norm"], scratch, self.G(g_n), self.G(v_n), d, Cg, K)
         dyg = self.new(G * B * Tp * Cg)

@@ -36,7 +36,7 @@ def view(ld, rows_per_batch=0, batch_stride=0, off=0):
 
 def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=None, bias=None, resid=None,
          aux_out=None, aux_in=None, act=ACT_NONE, out_f32=False, atomic=False, split_k=1, alpha=1.0, nbatch=1,
-         batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None):
+         batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None, split_stride=0):
     """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements."""
     p = L.GemmParams()
     p.A, p.B, p.C = _ptr(a), _ptr(b), _ptr(c)
@@ -50,6 +50,7 @@ def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=N
     p.M, p.N, p.K, p.a_rc, p.b_rc = M, N, K, int(a_rc), int(b_rc)
     p.act, p.out_f32, p.atomic = act, int(out_f32), int(atomic)
     p.nbatch, p.split_k, p.tr_mode, p.alpha = nbatch, split_k, tr_mode, alpha
+    p.split_stride = split_stride
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = prof.events()
@@ -255,3 +256,8 @@ def optimizer_step(p, g, m, v, shadow, gnorm_sq, n, lr, kind="adamw", beta1=0.9,
 def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):
     L.check(L.lib().smx_act_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(pre)), C.c_void_p(_ptr(dx)), M, N,
                                 C.byref(out_view), act, dtype, _stream()), "smx_act_bwd")
+
+
+def reduce_slabs(slabs, nsplit, n, stride, dst, accumulate=True):
+    L.check(L.lib().smx_reduce_slabs(C.c_void_p(_ptr(slabs)), nsplit, C.c_longlong(n), C.c_longlong(stride),
+                                     C.c_void_p(_ptr(dst)), int(accumulate), _stream()), "smx_reduce_slabs")

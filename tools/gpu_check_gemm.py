@@ -15,7 +15,7 @@ def view(ld, rpb=0, bs=0, off=0):
 
 
 def run(A, B, Cout, M, N, K, a_rc, b_rc, dtype, av=None, bv=None, cv=None, bias=None, resid=None, aux_out=None,
-        aux_in=None, act=0, out_f32=0, atomic=0, split_k=1, tr_mode=1, alpha=1.0, nbatch=1, ba=0, bb=0, bc=0):
+        aux_in=None, act=0, out_f32=0, atomic=0, split_k=1, tr_mode=1, alpha=1.0, nbatch=1, ba=0, bb=0, bc=0, split_stride=0):
     p = L.GemmParams()
     p.A, p.B, p.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
@@ -27,6 +27,7 @@ def run(A, B, Cout, M, N, K, a_rc, b_rc, dtype, av=None, bv=None, cv=None, bias=
     p.batch_a, p.batch_b, p.batch_c, p.batch_bias, p.batch_e = ba, bb, bc, 0, bc
     p.M, p.N, p.K, p.a_rc, p.b_rc = M, N, K, a_rc, b_rc
     p.act, p.out_f32, p.atomic, p.nbatch, p.split_k, p.tr_mode, p.alpha = act, out_f32, atomic, nbatch, split_k, tr_mode, alpha
+    p.split_stride = split_stride
     rc = lib.smx_gemm(C.byref(p), dtype, stream())
     assert rc == 0, rc
 
