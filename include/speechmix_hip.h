@@ -1,0 +1,126 @@
+/* speechmix_hip.h - C ABI of libspeechmix_hip.so, the MI355X (gfx950) kernel library under the SpeechMix
+ * drop-in classes.
+ *
+ * The reference (voidful/SpeechMix) is 100 % Python and has NO native interface of its own: its hot path calls
+ * PyTorch modules (ref:speechmix/model.py:148 `self.encoder_model(input_values)`, :135-136
+ * `self.decoder_model(inputs_embeds=..., decoder_input_ids=..., labels=...)`, :162 `self.length_adapters`, :165
+ * `self.enc_to_dec_proj`).  The entry points below are therefore what a Python binding (ctypes, see
+ * speechmix_amd/_lib.py, or any other FFI) binds INSTEAD of those module calls; each one cites the reference /
+ * transformers (TF:) code whose arithmetic it executes.  Conventions:
+ *   - plain C: raw device pointers + sizes, no torch types; the caller owns every buffer (PyTorch's caching
+ *     allocator in this repo) - kernels never allocate or free;
+ *   - every launcher enqueues on the given hipStream_t and returns 0 on success, a hipError_t (>0) or a negative
+ *     argument error (-22); nothing throws across the boundary;
+ *   - dtype: SMX_F32 (parity path) or SMX_BF16 (bf16 storage, fp32 accumulate / statistics);
+ *   - struct layouts are mirrored in speechmix_amd/_lib.py and checked at load time via smx_sizeof_*().
+ */
+#ifndef SPEECHMIX_HIP_H
+#define SPEECHMIX_HIP_H
+#include <hip/hip_runtime_api.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SMX_F32 = 0, SMX_BF16 = 1 };
+enum { SMX_ACT_NONE = 0, SMX_ACT_GELU = 1, SMX_ACT_RELU = 2 };
+
+/* logical row r of an operand -> element offset: off + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * ld
+ * (rows_per_batch <= 0: off + r * ld).  Lets a Conv1d be a GEMM over overlapping windows of a [B,T,C] activation. */
+typedef struct SmxRowView { long long batch_stride, ld, off; int rows_per_batch, _pad; } SmxRowView;
+
+/* C[m,n] (+)= epilogue(alpha * sum_k A(m,k) B(n,k)).  Replaces every nn.Linear / nn.Conv1d forward, data-gradient
+ * and weight-gradient on the path: ref:speechmix/model.py:92-102,162,165; TF:models/wav2vec2/modeling_wav2vec2.py:254-323
+ * (conv layers 1-6), :326-379 (positional conv, batched per group), :429-434, :466-572; TF:models/bart/modeling_bart.py:260-390,
+ * :939-940 (LM head).  a_rc / b_rc: operand stored [K, rows] (reduction index slow) - dgrad's W, both wgrad operands. */
+typedef struct SmxGemmParams {
+    const void *A, *B; void* C; const float* bias; const void* resid; void* aux_out; const void* aux_in;
+    SmxRowView a, b, c, e;
+    long long batch_a, batch_b, batch_c, batch_bias, batch_e;
+    int M, N, K, a_rc, b_rc, act, out_f32, atomic, nbatch, split_k, tr_mode; float alpha; long long split_stride;
+} SmxGemmParams;
+int smx_gemm(const SmxGemmParams* p, int dtype, hipStream_t stream);
+int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stride, float* dst, int accumulate, hipStream_t stream);
+
+/* LayerNorm / RMSNorm (+ fused positional-table add, + fused activation) forward and backward.
+ * TF:models/wav2vec2/modeling_wav2vec2.py:275-299, 429-434, 575-654; TF:models/bart/modeling_bart.py:507-549;
+ * TF:models/t5/modeling_t5.py:50-72. */
+typedef struct SmxNormParams {
+    const void *x, *pos; void *xsum_out, *y; const float *gamma, *beta; float *mean, *rstd;
+    int M, D, pos_period, pos_offset, rms, act; float eps;
+} SmxNormParams;
+typedef struct SmxNormBwdParams {
+    const void *dy, *x, *dres; void* dx; const float *gamma, *beta, *mean, *rstd; float *dgamma, *dbeta, *dpos, *partials;
+    int M, D, pos_period, pos_offset, rms, act;
+} SmxNormBwdParams;
+int smx_norm_fwd(const SmxNormParams* p, int dtype, hipStream_t stream);
+int smx_norm_bwd(const SmxNormBwdParams* p, int dtype, hipStream_t stream);
+
+/* softmax(Q K^T * scale + bias [+causal]) V and its backward (dQ, dK, dV), Q/K/V/O addressed inside fused
+ * projection buffers.  TF:models/wav2vec2/modeling_wav2vec2.py:466-548; TF:models/bart/modeling_bart.py:133-257;
+ * TF:models/t5/modeling_t5.py:176-369; TF:integrations/sdpa_attention.py:39-130. */
+typedef struct SmxAttnParams {
+    const void *Q, *K, *V; void* O; float* lse; const float* bias; const void* dO; void *dQ, *dK, *dV; float *delta, *dbias;
+    long long q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, do_bs, do_ld;
+    int B, H, Tq, Tk, D, causal; float scale;
+} SmxAttnParams;
+int smx_attention_fwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
+int smx_attention_bwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
+
+/* feature-extractor layer 0: Conv1d(1->C,k,stride) on the waveform, fused with GroupNorm+GELU ("group") or plain
+ * ("layer" extractor).  TF:models/wav2vec2/modeling_wav2vec2.py:301-323 / 275-299. */
+typedef struct SmxConv0Params {
+    const float *wave, *w, *cbias, *gamma, *beta; double* stats; void* y; const void* dy; double* bstats;
+    float *dw, *dcbias, *dgamma, *dbeta; int B, N, C, k, stride, T0, group; float eps; int tiles_per_block;
+} SmxConv0Params;
+int smx_conv0_fwd(const SmxConv0Params* p, int dtype, hipStream_t stream);
+int smx_conv0_bwd(const SmxConv0Params* p, int dtype, hipStream_t stream);
+
+/* positional conv helpers (group-major pack, weight_norm forward/backward). TF:...wav2vec2.py:326-379 */
+int smx_group_pack(const void* x, void* xg, int B, int T, int C, int G, int K, int pad_front, int dtype, hipStream_t stream);
+int smx_wn_fwd(const float* v, const float* g, void* wp, void* wf, float* norm, int C, int Cg, int K, int dtype, hipStream_t stream);
+int smx_wn_bwd(const float* dwp, const float* v, const float* g, const float* norm, float* scratch_s, float* dg, float* dv,
+               int C, int Cg, int K, hipStream_t stream);
+
+/* CrossEntropyLoss(ignore_index=-100, mean) + argmax + dlogits. TF:models/bart/modeling_bart.py:942-946; ref:speechmix/model.py:174 */
+typedef struct SmxCEParams {
+    const float* logits; const long long* labels; float* loss; long long* argmax; void* dlogits; float* lse;
+    int M, V; long long ldl, ldd; float gscale;
+} SmxCEParams;
+int smx_cross_entropy(const SmxCEParams* p, int dtype, hipStream_t stream);
+
+/* token embedding gather / scatter-add (TF:models/bart/modeling_bart.py:101-113), bias-gradient column sums,
+ * dtype casts, conv-weight re-layouts, activation backward, SpecAugment row masking
+ * (TF:models/wav2vec2/modeling_wav2vec2.py:1272-1316), element-wise add. */
+int smx_embed_fwd(const long long* ids, const void* table, void* out, int M, int D, float scale, int dtype, hipStream_t stream);
+int smx_embed_bwd(const long long* ids, const void* dy, float* dtable, int M, int D, float scale, int dtype, hipStream_t stream);
+int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream);
+int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
+int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream);
+int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k, int dtype, hipStream_t stream);
+int smx_unpack_conv_dw(const float* dwp, float* dw, int Co, int Ci, int k, hipStream_t stream);
+int smx_act_bwd(const void* dy, const void* pre, void* dx, int M, int N, const SmxRowView* out_view, int act, int dtype, hipStream_t stream);
+int smx_mask_rows(void* x, const int* rows, int nrows, const float* emb, int D, int dtype, hipStream_t stream);
+int smx_mask_rows_bwd(void* dx, const int* rows, int nrows, float* demb, int D, int dtype, hipStream_t stream);
+int smx_add(const void* a, const void* b, void* out, long long n, int dtype, hipStream_t stream);
+
+/* flat-buffer optimizer step (what HF Trainer's clip + optimizer.step do per tensor, ref:train.py:291-330) */
+typedef struct SmxOptParams {
+    float* p; const float* g; float *m, *v; void* shadow; const float* gnorm_sq; long long n;
+    float lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale, max_grad_norm; int kind;
+} SmxOptParams;
+int smx_sumsq(const float* g, long long n, float* out, hipStream_t stream);
+int smx_optimizer_step(const SmxOptParams* p, hipStream_t stream);
+
+/* ABI self-description */
+int smx_sizeof_SmxGemmParams(void);
+int smx_sizeof_SmxNormParams(void);
+int smx_sizeof_SmxNormBwdParams(void);
+int smx_sizeof_SmxAttnParams(void);
+int smx_sizeof_SmxConv0Params(void);
+int smx_sizeof_SmxCEParams(void);
+int smx_sizeof_SmxOptParams(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""CPU checks of the C-ABI boundary: the shared object builds/loads, exports every symbol that
+include/speechmix_hip.h declares, and its struct layouts agree with the ctypes mirrors and with the header
+as seen by a plain C compiler.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "speechmix_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from speechmix_amd import _lib as L
+    return L.lib()
+
+
+def _declared():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"^\s*int\s+(smx_\w+)\s*\(", src, flags=re.M)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/speechmix_hip.h but not exported"
+
+
+def test_struct_layouts_match_ctypes(lib):
+    from speechmix_amd import _lib as L
+    for name, st in (("SmxGemmParams", L.GemmParams), ("SmxNormParams", L.NormParams), ("SmxNormBwdParams", L.NormBwdParams),
+                     ("SmxAttnParams", L.AttnParams), ("SmxConv0Params", L.Conv0Params), ("SmxCEParams", L.CEParams),
+                     ("SmxOptParams", L.OptParams)):
+        assert getattr(lib, "smx_sizeof_" + name)() == C.sizeof(st), name
+
+
+def test_header_is_plain_c_and_agrees_with_library(lib, tmp_path):
+    """The header must be consumable from C (the drop-in boundary is a C ABI) and give the same sizes."""
+    prog = tmp_path / "sz.c"
+    prog.write_text('#define __HIP_PLATFORM_AMD__ 1\n#include <stdio.h>\n#include "speechmix_hip.h"\n'
+                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(SmxGemmParams), sizeof(SmxNormParams),'
+                    ' sizeof(SmxNormBwdParams), sizeof(SmxAttnParams), sizeof(SmxConv0Params), sizeof(SmxCEParams),'
+                    ' sizeof(SmxOptParams)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", str(prog), "-o", str(exe)],
+                   check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [getattr(lib, "smx_sizeof_" + n)() for n in ("SmxGemmParams", "SmxNormParams", "SmxNormBwdParams", "SmxAttnParams",
+                                                         "SmxConv0Params", "SmxCEParams", "SmxOptParams")]
+    assert got == want
+
+
+def test_product_path_fails_loudly_without_gpu_or_library():
+    import torch
+    from speechmix_amd import ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    t = torch.zeros(8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(t, t, t, 8, 8, 8, ops.F32)
+
+
+def test_product_package_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "speechmix_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
