@@ -85,6 +85,7 @@ int smx_wn_bwd(const float* dwp, const float* v, const float* g, const float* no
 typedef struct SmxCEParams {
     const float* logits; const long long* labels; float* loss; long long* argmax; void* dlogits; float* lse;
     int M, V; long long ldl, ldd; float gscale;
+    const float* logits_t; float* kld; float kld_scale;   /* SpeechMixSelf KLD term, ref:speechmix/model.py:257-259 */
 } SmxCEParams;
 int smx_cross_entropy(const SmxCEParams* p, int dtype, hipStream_t stream);
 
@@ -102,6 +103,11 @@ int smx_act_bwd(const void* dy, const void* pre, void* dx, int M, int N, const S
 int smx_mask_rows(void* x, const int* rows, int nrows, const float* emb, int D, int dtype, hipStream_t stream);
 int smx_mask_rows_bwd(void* dx, const int* rows, int nrows, float* demb, int D, int dtype, hipStream_t stream);
 int smx_add(const void* a, const void* b, void* out, long long n, int dtype, hipStream_t stream);
+/* SpeechMixSelf hidden-state matching (ref:speechmix/model.py:247-255): row softmax fwd/bwd, MSE (+gradient), fp32 -> T add */
+int smx_softmax_rows(float* x, int R, int Cn, hipStream_t stream);
+int smx_softmax_rows_bwd(const float* p, const float* dp, float* dx, int R, int Cn, float scale, hipStream_t stream);
+int smx_mse(const float* a, const float* b, float* loss, float* da, long long n, float gscale, hipStream_t stream);
+int smx_add_f32_into(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 
 /* flat-buffer optimizer step (what HF Trainer's clip + optimizer.step do per tensor, ref:train.py:291-330) */
 typedef struct SmxOptParams {

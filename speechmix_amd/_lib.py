@@ -90,7 +90,8 @@ class Conv0Params(C.Structure):
 class CEParams(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("labels", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p),
                 ("dlogits", C.c_void_p), ("lse", C.c_void_p), ("M", C.c_int), ("V", C.c_int),
-                ("ldl", C.c_longlong), ("ldd", C.c_longlong), ("gscale", C.c_float)]
+                ("ldl", C.c_longlong), ("ldd", C.c_longlong), ("gscale", C.c_float),
+                ("logits_t", C.c_void_p), ("kld", C.c_void_p), ("kld_scale", C.c_float)]
 
 
 class OptParams(C.Structure):

@@ -205,6 +205,10 @@ struct SmxCEParams {
     int M, V;
     long long ldl, ldd;
     float gscale;              // multiplies dlogits (upstream gradient)
+    // SpeechMixSelf (ref:speechmix/model.py:257-259): KLDivLoss(batchmean)(log_softmax(logits), softmax(logits_t))
+    const float* logits_t;     // teacher logits [M, ldl] or null
+    float* kld;                // scalar, atomically accumulated (already divided by the batch size)
+    float kld_scale;           // 1 / batch size
 };
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
@@ -247,12 +251,35 @@ __global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
     const long long lab = p.labels[row];
     const bool valid = lab != -100;
     if (valid && tid == 0) atomicAdd(p.loss, (lse - z[lab]) / nvalid);
+    float lse_t = 0.f;
+    const float* zt = p.logits_t ? p.logits_t + (long long)row * p.ldl : nullptr;
+    if (zt) {
+        float mt = -INFINITY;
+        for (int j = tid; j < p.V; j += 256) mt = fmaxf(mt, zt[j]);
+        mt = block_max(mt, sh);
+        float st = 0.f;
+        for (int j = tid; j < p.V; j += 256) st += __expf(zt[j] - mt);
+        st = block_sum(st, sh);
+        lse_t = mt + __logf(st);
+        float kl = 0.f;
+        for (int j = tid; j < p.V; j += 256) {
+            const float lpt = zt[j] - lse_t;
+            kl += __expf(lpt) * (lpt - (z[j] - lse));
+        }
+        kl = block_sum(kl, sh);
+        if (tid == 0 && p.kld) atomicAdd(p.kld, kl * p.kld_scale);
+    }
     if (p.dlogits) {
         T* d = reinterpret_cast<T*>(p.dlogits) + (long long)row * p.ldd;
         const float coef = valid ? p.gscale / nvalid : 0.f;
+        const float kcoef = p.gscale * p.kld_scale;
         for (int j = tid; j < p.ldd; j += 256) {
             float g = 0.f;
-            if (j < p.V && valid) g = (__expf(z[j] - lse) - (j == lab ? 1.f : 0.f)) * coef;
+            if (j < p.V) {
+                const float ps = __expf(z[j] - lse);
+                if (valid) g = (ps - (j == lab ? 1.f : 0.f)) * coef;
+                if (zt) g += (ps - __expf(zt[j] - lse_t)) * kcoef;
+            }
             Cvt<T>::st(d + j, g);
         }
     }
@@ -359,6 +386,80 @@ extern "C" int smx_act_bwd(const void* dy, const void* pre, void* dx, int M, int
     int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)pre, (bf16_t*)dx, M, N, *ov, act);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)dy, (const float*)pre, (float*)dx, M, N, *ov, act);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- SpeechMixSelf hidden-state matching (fp32, tiny)
+// ref:speechmix/model.py:247-255: attn = softmax(bmm(H_text, H_speech.view(B,d,-1)) / sqrt(d)); MSE(bmm(attn,H_speech), H_text)
+__global__ void softmax_rows_kernel(float* __restrict__ x, int R, int Cn) {   // in place, one wave per row
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    float* r = x + (long long)row * Cn;
+    float m = -INFINITY;
+    for (int j = lane; j < Cn; j += 64) m = fmaxf(m, r[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Cn; j += 64) s += __expf(r[j] - m);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int j = lane; j < Cn; j += 64) r[j] = __expf(r[j] - m) * inv;
+}
+extern "C" int smx_softmax_rows(float* x, int R, int Cn, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, x, R, Cn);
+    SMX_CHECK_LAUNCH();
+}
+// dx = scale * p * (dp - sum_j p_j dp_j)
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ dx,
+                                        int R, int Cn, float scale) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* pr = p + (long long)row * Cn;
+    const float* dr = dp + (long long)row * Cn;
+    float s = 0.f;
+    for (int j = lane; j < Cn; j += 64) s += pr[j] * dr[j];
+    s = wave_sum(s);
+    for (int j = lane; j < Cn; j += 64) dx[(long long)row * Cn + j] = scale * pr[j] * (dr[j] - s);
+}
+extern "C" int smx_softmax_rows_bwd(const float* p, const float* dp, float* dx, int R, int Cn, float scale, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, p, dp, dx, R, Cn, scale);
+    SMX_CHECK_LAUNCH();
+}
+// loss += mean((a-b)^2);  da = gscale * 2 (a-b) / n
+__global__ void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, float* loss, float* __restrict__ da,
+                           long long n, float gscale) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        s += d * d;
+        if (da) da[i] = gscale * 2.f * d * inv;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+}
+extern "C" int smx_mse(const float* a, const float* b, float* loss, float* da, long long n, float gscale, hipStream_t stream) {
+    (void)hipGetLastError();
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, stream, a, b, loss, da, n, gscale);
+    SMX_CHECK_LAUNCH();
+}
+// dst (dtype T) += src (fp32)
+template <typename T>
+__global__ void add_f32_into_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        Cvt<T>::st(dst + i, Cvt<T>::ld(dst + i) + src[i]);
+}
+extern "C" int smx_add_f32_into(const float* src, void* dst, long long n, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(add_f32_into_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(add_f32_into_kernel<float>, dim3(blocks), dim3(256), 0, stream, src, (float*)dst, n);
     else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }

@@ -775,7 +775,45 @@ class Engine:
         sv["logits"], sv["V"], sv["Vp"] = logits, V, Vp
         return logits, enc, sv
 
-    def lm_bwd(self, dlogits, sv, gscale):
+    # ------------------------------------------------------------------ SpeechMixSelf hidden-state matching
+    def self_mse(self, enc_s, enc_t, B, S, Lt, want_grad=True):
+        """ref:speechmix/model.py:247-255.  enc_s [B*S,d] speech-side LM-encoder output, enc_t [B*Lt,d] text side.
+        attn = softmax(bmm(H_t, H_s.view(B,d,-1)) / sqrt(d)); mse = MSE(bmm(attn, H_s), H_t).  The `.view(B,d,-1)`
+        is a reinterpretation of H_s's memory (not a transpose) and is reproduced as such.  Tiny matrices: done in
+        fp32 with the simple GEMM kernel.  Returns (mse loss [1] fp32, dH_s [B*S,d] fp32 or None)."""
+        d = self.lc.d_model
+        hs = self.new(B * S, d, dt=torch.float32)
+        ht = self.new(B * Lt, d, dt=torch.float32)
+        ops.cast_to_f32(enc_s, hs, B * S * d, self.dt)
+        ops.cast_to_f32(enc_t, ht, B * Lt * d, self.dt)
+        attn = self.new(B * Lt, S, dt=torch.float32)
+        scale = 1.0 / math.sqrt(d)
+        # A[b] = H_t[b] [Lt,d] @ R[b] [d,S]   with R = H_s[b] memory read as [d,S]
+        ops.gemm(ht, hs, attn, Lt, S, d, F32, b_rc=True, bv=view(S), cv=view(S), alpha=scale, nbatch=B,
+                 batch_a=Lt * d, batch_b=S * d, batch_c=Lt * S)
+        ops.softmax_rows(attn, B * Lt, S)
+        proj = self.new(B * Lt, d, dt=torch.float32)
+        ops.gemm(attn, hs, proj, Lt, d, S, F32, b_rc=True, av=view(S), bv=view(d), cv=view(d), nbatch=B,
+                 batch_a=Lt * S, batch_b=S * d, batch_c=Lt * d)
+        loss = self.zeros(1, dt=torch.float32)
+        dproj = self.new(B * Lt, d, dt=torch.float32) if want_grad else None
+        ops.mse(proj, ht, loss, dproj, B * Lt * d)
+        if not want_grad:
+            return loss, None
+        # d attn = dproj @ H_s^T ; dH_s = attn^T @ dproj ; dA = softmax_bwd(attn, dattn)/sqrt(d) ; dR = H_t^T @ dA
+        dattn = self.new(B * Lt, S, dt=torch.float32)
+        ops.gemm(dproj, hs, dattn, Lt, S, d, F32, av=view(d), bv=view(d), cv=view(S), nbatch=B, batch_a=Lt * d,
+                 batch_b=S * d, batch_c=Lt * S)
+        dhs = self.new(B * S, d, dt=torch.float32)
+        ops.gemm(attn, dproj, dhs, S, d, Lt, F32, a_rc=True, b_rc=True, av=view(S), bv=view(d), cv=view(d), nbatch=B,
+                 batch_a=Lt * S, batch_b=Lt * d, batch_c=S * d)
+        dA = self.new(B * Lt, S, dt=torch.float32)
+        ops.softmax_rows_bwd(attn, dattn, dA, B * Lt, S, scale)
+        ops.gemm(ht, dA, dhs, d, S, Lt, F32, a_rc=True, b_rc=True, av=view(d), bv=view(S), cv=view(S), atomic=2, nbatch=B,
+                 batch_a=Lt * d, batch_b=Lt * S, batch_c=S * d)
+        return loss, dhs
+
+    def lm_bwd(self, dlogits, sv, gscale, extra_denc=None):
         """dlogits [B*Ld, Vp] compute dtype.  Returns grad wrt inputs_embeds [B*S, d] (or None for token input)."""
         lc, lp = self.lc, self.lp
         d, B, S, Ld, t5 = lc.d_model, sv["B"], sv["S"], sv["Ld"], sv["t5"]
@@ -809,6 +847,8 @@ class Engine:
             ops.embed_bwd(sv["dec_ids"], dy, self.G(emb_name), Md, d, escale, self.dt)
         # ---- text encoder
         dh = denc[0]
+        if extra_denc is not None:      # SpeechMixSelf: gradient of the hidden-state matching loss (fp32)
+            ops.add_f32_into(extra_denc, dh, Ms * d, self.dt)
         if t5:
             dh = self.ln_bwd(dh, sv["enc_final_ln"], lp + "encoder.final_layer_norm.weight", None, Ms, d, rms=True)
         elif lc.model_type == "mbart":
@@ -829,8 +869,36 @@ class Engine:
         return dh
 
     # ------------------------------------------------------------------ whole step
-    def forward(self, wave, dec_ids, labels, training=False, prompt_embeds=None):
-        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None."""
+    def lm_losses(self, e, dec_ids, labels, B, S, Ld, text_ids=None, training=False, want_grad=True):
+        """LM on `inputs_embeds` e [B*S,d] (+ optional SpeechMixSelf teacher pass on text_ids) -> losses and dlogits.
+        Plain: CE (ref:speechmix/model.py:132-137).  Self: CE + KLD(batchmean) + MSE (ref:speechmix/model.py:235-266)."""
+        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training)
+        V, Vp = lsv["V"], lsv["Vp"]
+        M = B * Ld
+        argmax = self.new(M, dt=torch.int64)
+        out = dict(logits=logits, lm_enc_last=enc, argmax=argmax.view(B, Ld), lsv=lsv, loss=None, dlogits=None, extra_denc=None)
+        if labels is None:
+            ops.cross_entropy(logits, None, None, argmax, None, M, V, Vp, Vp, self.dt)
+            return out
+        lab = labels.reshape(-1).contiguous()
+        ce = self.zeros(1, dt=torch.float32)
+        dlogits = self.new(M, Vp) if want_grad else None
+        if text_ids is None:
+            ops.cross_entropy(logits, lab, ce, argmax, dlogits, M, V, Vp, Vp, self.dt)
+            out.update(loss=ce, ce=ce, dlogits=dlogits)
+            return out
+        Lt = text_ids.shape[1]
+        logits_t, enc_t, _ = self.lm_fwd(None, text_ids.reshape(-1).contiguous(), dec_ids.reshape(-1).contiguous(), B, Lt, Ld,
+                                         False)
+        kld = self.zeros(1, dt=torch.float32)
+        ops.cross_entropy(logits, lab, ce, argmax, dlogits, M, V, Vp, Vp, self.dt, logits_t=logits_t, kld=kld,
+                          kld_scale=1.0 / B)
+        mse, dhs = self.self_mse(enc, enc_t, B, S, Lt, want_grad=want_grad)
+        out.update(loss=kld + ce + mse, ce=ce, kld=kld, mse=mse, dlogits=dlogits, extra_denc=dhs)
+        return out
+
+    def forward(self, wave, dec_ids, labels, training=False, prompt_embeds=None, text_ids=None):
+        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf)."""
         self.st.refresh_shadow()
         B, N = wave.shape
         Ld = dec_ids.shape[1]
@@ -838,21 +906,11 @@ class Engine:
         e, S, bsv = self.bridge_fwd(x, B, ssv["T"])
         if prompt_embeds is not None:
             raise NotImplementedError("input_text_prompt is not implemented in the HIP engine yet")
-        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training)
-        V, Vp = lsv["V"], lsv["Vp"]
-        M = B * Ld
-        argmax = self.new(M, dt=torch.int64)
-        loss = None
-        dlogits = None
-        if labels is not None:
-            loss = self.zeros(1, dt=torch.float32)
-            dlogits = self.new(M, Vp)
-            ops.cross_entropy(logits, labels.reshape(-1).contiguous(), loss, argmax, dlogits, M, V, Vp, Vp, self.dt)
-        else:
-            ops.cross_entropy(logits, None, None, argmax, None, M, V, Vp, Vp, self.dt)
-        self.saved = dict(speech=ssv, bridge=bsv, lm=lsv, dlogits=dlogits, B=B, Ld=Ld)
-        return dict(loss=loss, argmax=argmax.view(B, Ld), logits=logits, enc_last=x, lm_enc_last=enc, inputs_embeds=e,
-                    S=S, T=ssv["T"], post_adapter=bsv["post_adapter"], hidden=ssv["hidden"])
+        lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids, training=training)
+        self.saved = dict(speech=ssv, bridge=bsv, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], B=B, Ld=Ld)
+        return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=x, lm_enc_last=lo["lm_enc_last"],
+                    inputs_embeds=e, S=S, T=ssv["T"], post_adapter=bsv["post_adapter"], hidden=ssv["hidden"],
+                    parts={k: lo[k] for k in ("ce", "kld", "mse") if k in lo})
 
     def backward(self, gscale=1.0, zero_grads=True):
         sv = self.saved
@@ -860,7 +918,10 @@ class Engine:
             raise RuntimeError("backward() needs a forward() with labels")
         if zero_grads:
             self.st.grad.zero_()
-        de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale)
+        extra = sv.get("extra_denc")
+        if extra is not None and gscale != 1.0:
+            extra = extra * gscale
+        de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
         self._stage("lm")
         dx = self.bridge_bwd(de, sv["bridge"])
         self._stage("bridge")

@@ -94,7 +94,9 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, wave, dec_ids, labels, training, anchor, *params):
-        out = model.engine.forward(wave, dec_ids, labels, training=training)
+        text_ids = model._pending_text_ids
+        model._pending_text_ids = None
+        out = model.engine.forward(wave, dec_ids, labels, training=training, text_ids=text_ids)
         ctx.model = model
         ctx.n_params = len(params)
         model._last = out
@@ -113,6 +115,8 @@ class _StepFn(torch.autograd.Function):
 
 
 class SpeechMixEED(nn.Module):
+    _uses_text_ids = False      # SpeechMixSelf consumes `text_input_ids`; EED ignores them like the reference
+
     def __init__(self, speech_model_config, nlp_model_config, share_layer_ratio=0, down_scale=8, weighted_sum=False,
                  fixed_parameters=False,
                  fixed_except=["layer_norm", "encoder_attn", 'enc_to_dec_proj', 'length_adapter', "layernorm_embedding",
@@ -190,6 +194,7 @@ class SpeechMixEED(nn.Module):
         self.autograd_param_inputs = bool(kwargs.get("autograd_param_inputs", False))
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self._last = None
+        self._pending_text_ids = None
         self.store = None
         self.engine = None
         if self.device.type == "cuda":
@@ -316,7 +321,7 @@ class SpeechMixEED(nn.Module):
 
     # ------------------------------------------------------------------ forward (ref:speechmix/model.py:139-177)
     def forward(self, input_values, input_text_prompt=None, decoder_input_ids=None, labels=None,
-                return_model_detail=False):
+                return_model_detail=False, text_input_ids=None):
         self._need_engine()
         lc = self.decoder_model.config
         wave = self._prep_wave(input_values)
@@ -333,12 +338,14 @@ class SpeechMixEED(nn.Module):
         training = self.training and self.encoder_model.training
         return_dict = {}
         want_grad = torch.is_grad_enabled() and lab is not None and len(self.list_grad) > 0
+        text = text_input_ids.to(self.device).contiguous() if (text_input_ids is not None and self._uses_text_ids) else None
         if want_grad:
             params = tuple(self.store.params.values()) if self.autograd_param_inputs else ()
+            self._pending_text_ids = text
             loss = _StepFn.apply(self, wave, dec, lab, training, self._anchor, *params)
             out = self._last
         else:
-            out = self.engine.forward(wave, dec, lab, training=False)
+            out = self.engine.forward(wave, dec, lab, training=False, text_ids=text)
             loss = out["loss"].view(()) if out["loss"] is not None else None
             self.engine.saved = None
         B, Ld = dec.shape
@@ -354,6 +361,8 @@ class SpeechMixEED(nn.Module):
             return_dict["encoder_last_hidden_state"] = out["enc_last"].view(B, T, d).float()
             return_dict["inputs_embeds"] = out["inputs_embeds"].view(B, S, dd).float()
             return_dict["lm_encoder_last_hidden"] = out["lm_enc_last"].view(B, S, dd).float()
+            for k, v in out.get("parts", {}).items():
+                return_dict[k + "_loss"] = v.view(())
         return_dict["logits"] = out["argmax"]
         if loss is not None:
             return_dict["loss"] = loss
@@ -373,3 +382,41 @@ class SpeechMixFixed(SpeechMixEED):
         if fixed_nlp:
             for name, param in self.decoder_model.named_parameters():
                 param.requires_grad = False
+
+
+class SpeechMixSelf(SpeechMixEED):
+    """ref:speechmix/model.py:225-266: frozen LM; loss = KLD(speech logits || text logits) + CE + MSE(attention-pooled
+    speech hidden, text hidden).  Unlike the reference at this commit, `forward` accepts
+    `text_input_ids` and forwards it, as the HF twin's signature intends (ref:speechmix/hf_model.py:378-394)."""
+    _uses_text_ids = True
+
+    def custom_modules(self, **kwargs):
+        self.encoder_model.eval()
+        self.decoder_model.eval()
+        for name, param in self.decoder_model.named_parameters():
+            if param.requires_grad:
+                param.requires_grad = False
+
+    def cal_loss(self, inputs_embeds=None, text_input_ids=None, attention_mask=None, decoder_input_ids=None, labels=None):
+        """Direct (no-autograd) evaluation of the three losses on given `inputs_embeds`, like calling the
+        reference's cal_loss: returns an output with .logits [B,L,V], .loss and the separate terms."""
+        self._need_engine()
+        eng, lc = self.engine, self.decoder_model.config
+        self.store.refresh_shadow()
+        if decoder_input_ids is None and labels is not None:
+            decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
+        dec = decoder_input_ids.to(self.device).contiguous()
+        B, Ld = dec.shape
+        emb = inputs_embeds.to(self.device, ops.torch_dtype(self.compute_dtype)).contiguous()
+        S = emb.shape[1]
+        lab = labels.to(self.device).contiguous() if labels is not None else None
+        text = text_input_ids.to(self.device).contiguous() if (text_input_ids is not None and lab is not None) else None
+        lo = eng.lm_losses(emb.view(B * S, -1), dec, lab, B, S, Ld, text_ids=text, want_grad=False)
+        V = lo["lsv"]["V"]
+        out = _Out(logits=lo["logits"].view(B, Ld, -1)[:, :, :V], encoder_last_hidden_state=lo["lm_enc_last"].view(B, S, -1).float())
+        if lo["loss"] is not None:
+            out["loss"] = lo["loss"].view(())
+            for k in ("ce", "kld", "mse"):
+                if k in lo:
+                    out[k + "_loss"] = lo[k].view(())
+        return out

@@ -203,8 +203,10 @@ def colsum(x, out, M, N, ld, dtype, alpha=1.0):
                                dtype, _stream()), "smx_colsum")
 
 
-def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, gscale=1.0, lse=None):
-    p = L.CEParams(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(argmax), _ptr(dlogits), _ptr(lse), M, V, ldl, ldd, gscale)
+def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, gscale=1.0, lse=None, logits_t=None,
+                  kld=None, kld_scale=0.0):
+    p = L.CEParams(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(argmax), _ptr(dlogits), _ptr(lse), M, V, ldl, ldd, gscale,
+                   _ptr(logits_t), _ptr(kld), kld_scale)
     L.check(L.lib().smx_cross_entropy(C.byref(p), dtype, _stream()), "smx_cross_entropy")
 
 
@@ -261,3 +263,22 @@ def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):
 def reduce_slabs(slabs, nsplit, n, stride, dst, accumulate=True):
     L.check(L.lib().smx_reduce_slabs(C.c_void_p(_ptr(slabs)), nsplit, C.c_longlong(n), C.c_longlong(stride),
                                      C.c_void_p(_ptr(dst)), int(accumulate), _stream()), "smx_reduce_slabs")
+
+
+def softmax_rows(x, R, Cn):
+    L.check(L.lib().smx_softmax_rows(C.c_void_p(_ptr(x)), R, Cn, _stream()), "smx_softmax_rows")
+
+
+def softmax_rows_bwd(p, dp, dx, R, Cn, scale):
+    L.check(L.lib().smx_softmax_rows_bwd(C.c_void_p(_ptr(p)), C.c_void_p(_ptr(dp)), C.c_void_p(_ptr(dx)), R, Cn,
+                                         C.c_float(scale), _stream()), "smx_softmax_rows_bwd")
+
+
+def mse(a, b, loss, da, n, gscale=1.0):
+    L.check(L.lib().smx_mse(C.c_void_p(_ptr(a)), C.c_void_p(_ptr(b)), C.c_void_p(_ptr(loss)), C.c_void_p(_ptr(da)),
+                            C.c_longlong(n), C.c_float(gscale), _stream()), "smx_mse")
+
+
+def add_f32_into(src, dst, n, dtype):
+    L.check(L.lib().smx_add_f32_into(C.c_void_p(_ptr(src)), C.c_void_p(_ptr(dst)), C.c_longlong(n), dtype, _stream()),
+            "smx_add_f32_into")
