@@ -100,3 +100,8 @@ class OptParams(C.Structure):
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("bias_c1", C.c_float), ("bias_c2", C.c_float),
                 ("grad_scale", C.c_float), ("max_grad_norm", C.c_float), ("kind", C.c_int)]
+
+
+class WsumParams(C.Structure):
+    _fields_ = [("h", C.c_void_p * 40), ("w", C.c_void_p), ("out", C.c_void_p), ("dy", C.c_void_p), ("dots", C.c_void_p),
+                ("dw", C.c_void_p), ("sw", C.c_void_p), ("n", C.c_longlong), ("L1", C.c_int)]

@@ -463,3 +463,120 @@ extern "C" int smx_add_f32_into(const float* src, void* dst, long long n, int dt
     else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------- layer-weighted sum of the speech-encoder hidden states
+// ref:speechmix/hf_model.py:411-423: out = sum_l softmax(w)_l * h_l over the L+1 hidden states (HBM-bound, L+1 reads).
+#define WS_MAXL 40
+struct SmxWsumParams {
+    const void* h[WS_MAXL];   // L+1 hidden states [n] (dtype T)
+    const float* w;           // raw weights [L+1] (softmax applied here)
+    void* out;                // fwd: [n] output          | bwd: unused
+    const void* dy;           // bwd: upstream gradient [n]
+    float* dots;              // bwd: [L+1] fp32 scratch (zeroed here): sum dy * h_l
+    float* dw;                // bwd: gradient of the raw weights [L+1] (accumulated)
+    float* sw;                // softmax(w) written out [L+1] (fwd) / read (bwd)
+    long long n;
+    int L1;                   // number of states
+};
+template <typename T>
+__global__ void wsum_fwd_kernel(SmxWsumParams p) {
+    __shared__ float sw[WS_MAXL];
+    if (threadIdx.x == 0) {
+        float m = -INFINITY, s = 0.f;
+        for (int l = 0; l < p.L1; ++l) m = fmaxf(m, p.w[l]);
+        for (int l = 0; l < p.L1; ++l) { sw[l] = __expf(p.w[l] - m); s += sw[l]; }
+        for (int l = 0; l < p.L1; ++l) { sw[l] /= s; if (blockIdx.x == 0 && p.sw) p.sw[l] = sw[l]; }
+    }
+    __syncthreads();
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long step = (long long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= p.n; i += step) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < p.L1; ++l) {
+            float v[8];
+            load8(reinterpret_cast<const T*>(p.h[l]) + i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(sw[l], v[e], acc[e]);
+        }
+        store8(reinterpret_cast<T*>(p.out) + i, acc);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void wsum_dots_kernel(SmxWsumParams p) {
+    __shared__ float sh[16];
+    long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long step = (long long)gridDim.x * blockDim.x * 8;
+    for (int l = 0; l < p.L1; ++l) {
+        float s = 0.f;
+        for (long long i = i0; i + 8 <= p.n; i += step) {
+            float a[8], b[8];
+            load8(reinterpret_cast<const T*>(p.dy) + i, a);
+            load8(reinterpret_cast<const T*>(p.h[l]) + i, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(a[e], b[e], s);
+        }
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) atomicAdd(p.dots + l, s);
+    }
+}
+__global__ void wsum_dw_kernel(SmxWsumParams p) {   // softmax backward on L+1 values
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float dot = 0.f;
+    for (int l = 0; l < p.L1; ++l) dot += p.sw[l] * p.dots[l];
+    for (int l = 0; l < p.L1; ++l) p.dw[l] += p.sw[l] * (p.dots[l] - dot);
+}
+extern "C" int smx_sizeof_SmxWsumParams(void) { return (int)sizeof(SmxWsumParams); }
+extern "C" int smx_weighted_sum_fwd(const SmxWsumParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    SmxWsumParams p = *pp;
+    if (p.L1 < 1 || p.L1 > WS_MAXL || (p.n & 7)) return SMX_EINVAL;
+    long long blocks = (p.n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(wsum_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(wsum_fwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+extern "C" int smx_weighted_sum_bwd(const SmxWsumParams* pp, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    SmxWsumParams p = *pp;
+    if (p.L1 < 1 || p.L1 > WS_MAXL || (p.n & 7) || !p.dots || !p.dw || !p.sw) return SMX_EINVAL;
+    (void)hipMemsetAsync(p.dots, 0, sizeof(float) * p.L1, stream);
+    long long blocks = (p.n / 8 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(wsum_dots_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(wsum_dots_kernel<float>, dim3(blocks), dim3(256), 0, stream, p);
+    else return SMX_EINVAL;
+    hipLaunchKernelGGL(wsum_dw_kernel, dim3(1), dim3(64), 0, stream, p);
+    SMX_CHECK_LAUNCH();
+}
+// y += a[idx] * x   (a: device scalar array; adds the weighted-sum gradient share to a hidden state's gradient)
+template <typename T>
+__global__ void axpy_dev_kernel(T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ a, int idx, long long n, int init) {
+    const float s = a[idx];
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long step = (long long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += step) {
+        float u[8], v[8];
+        load8(x + i, v);
+        if (init) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = s * v[e];
+        } else {
+            load8(y + i, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = fmaf(s, v[e], u[e]);
+        }
+        store8(y + i, u);
+    }
+}
+extern "C" int smx_axpy_dev(void* y, const void* x, const float* a, int idx, long long n, int init, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n & 7) return SMX_EINVAL;
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(axpy_dev_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (bf16_t*)y, (const bf16_t*)x, a, idx, n, init);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(axpy_dev_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)y, (const float*)x, a, idx, n, init);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}

@@ -594,7 +594,9 @@ class Engine:
         sv["hidden"] = hidden
         return x, sv
 
-    def speech_bwd(self, dx, sv):
+    def speech_bwd(self, dx, sv, ws=None):
+        """dx: grad wrt the encoder's last hidden state.  ws = (dxw, sw): layer-weighted-sum mode - every hidden
+        state l additionally receives sw[l] * dxw (ref:speechmix/hf_model.py:411-423)."""
         ec, ep = self.ec, self.ep
         d = ec.hidden_size
         B, T = sv["B"], sv["T"]
@@ -602,11 +604,17 @@ class Engine:
         C = ec.conv_dim[-1]
         stable = ec.do_stable_layer_norm
         act = _act_id(ec.hidden_act)
+        if ws is not None:
+            dxw, sw = ws
+            dx = self.new(M, d)
+            ops.axpy_dev(dx, dxw, sw, self.L, M * d, True, self.dt)
         if stable:
             dx = self.ln_bwd(dx, sv["final_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
         for i in range(self.L - 1, -1, -1):
             if sv["layers"][i] is not None:
                 dx = self.layer_bwd(dx, sv["layers"][i], self._w2v2_layer_names(i), stable, act)
+            if ws is not None:
+                ops.axpy_dev(dx, ws[0], ws[1], i, M * d, False, self.dt)
             self._stage(f"enc_layer{i}")
         if not stable:
             dx = self.ln_bwd(dx, sv["enc_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
@@ -897,19 +905,42 @@ class Engine:
         out.update(loss=kld + ce + mse, ce=ce, kld=kld, mse=mse, dlogits=dlogits, extra_denc=dhs)
         return out
 
-    def forward(self, wave, dec_ids, labels, training=False, prompt_embeds=None, text_ids=None):
-        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf)."""
+    def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False):
+        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf);
+        prompt_ids [P] int64: token ids of a text prompt whose embeddings are prepended to every clip
+        (ref:speechmix/model.py:168-171, batch-expanded like ref:speechmix/hf_model.py:433-436)."""
         self.st.refresh_shadow()
         B, N = wave.shape
         Ld = dec_ids.shape[1]
         x, ssv = self.speech_fwd(wave, B, N, training)
-        e, S, bsv = self.bridge_fwd(x, B, ssv["T"])
-        if prompt_embeds is not None:
-            raise NotImplementedError("input_text_prompt is not implemented in the HIP engine yet")
+        T, d = ssv["T"], self.ec.hidden_size
+        ws = None
+        xin = x
+        if weighted_sum:
+            hidden = ssv["hidden"]
+            sw = self.new(len(hidden), dt=torch.float32)
+            xin = self.new(B * T, d)
+            ops.weighted_sum_fwd(hidden, self.P("weights_sum"), xin, sw, B * T * d, self.dt)
+            ws = sw
+        e, S, bsv = self.bridge_fwd(xin, B, T)
+        P = 0
+        if prompt_ids is not None:
+            lc = self.lc
+            P = prompt_ids.numel()
+            dd = lc.d_model
+            t5 = lc.model_type == "t5"
+            emb_name = self.lp + ("shared.weight" if t5 else "model.shared.weight")
+            escale = math.sqrt(dd) if (lc.scale_embedding and not t5) else 1.0
+            pe = self.new(P, dd)
+            ops.embed_fwd(prompt_ids, self.W(emb_name), pe, P, dd, escale, self.dt)
+            # concatenation along time is pure data movement
+            e = torch.cat((pe.view(1, P, dd).expand(B, P, dd), e.view(B, S, dd)), 1).contiguous().view(B * (P + S), dd)
+            S = S + P
         lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids, training=training)
-        self.saved = dict(speech=ssv, bridge=bsv, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], B=B, Ld=Ld)
+        self.saved = dict(speech=ssv, bridge=bsv, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], B=B, Ld=Ld,
+                          ws=ws, P=P, prompt_ids=prompt_ids)
         return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=x, lm_enc_last=lo["lm_enc_last"],
-                    inputs_embeds=e, S=S, T=ssv["T"], post_adapter=bsv["post_adapter"], hidden=ssv["hidden"],
+                    inputs_embeds=e, S=S, T=T, post_adapter=bsv["post_adapter"], hidden=ssv["hidden"], sw=ws,
                     parts={k: lo[k] for k in ("ce", "kld", "mse") if k in lo})
 
     def backward(self, gscale=1.0, zero_grads=True):
@@ -922,9 +953,31 @@ class Engine:
         if extra is not None and gscale != 1.0:
             extra = extra * gscale
         de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
+        P = sv.get("P", 0)
+        if P:
+            lc, B = self.lc, sv["B"]
+            dd = lc.d_model
+            S2 = de.shape[0] // B
+            de3 = de.view(B, S2, dd)
+            t5 = lc.model_type == "t5"
+            emb_name = self.lp + ("shared.weight" if t5 else "model.shared.weight")
+            if self.tr(emb_name):
+                escale = math.sqrt(dd) if (lc.scale_embedding and not t5) else 1.0
+                dp = de3[:, :P].contiguous().view(B * P, dd)
+                ops.embed_bwd(sv["prompt_ids"].repeat(B).contiguous(), dp, self.G(emb_name), B * P, dd, escale, self.dt)
+            de = de3[:, P:].contiguous().view(B * (S2 - P), dd)
         self._stage("lm")
         dx = self.bridge_bwd(de, sv["bridge"])
+        ws = None
+        if sv.get("ws") is not None:
+            ssv = sv["speech"]
+            hidden = ssv["hidden"]
+            n = ssv["B"] * ssv["T"] * self.ec.hidden_size
+            dots = self.new(len(hidden), dt=torch.float32)
+            if self.tr("weights_sum"):
+                ops.weighted_sum_bwd(hidden, self.P("weights_sum"), dx, dots, self.G("weights_sum"), sv["ws"], n, self.dt)
+            ws = (dx, sv["ws"])
         self._stage("bridge")
-        self.speech_bwd(dx, sv["speech"])
+        self.speech_bwd(dx, sv["speech"], ws=ws)
         self._stage("frontend")
         self.saved = None

@@ -94,9 +94,10 @@ class _StepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, wave, dec_ids, labels, training, anchor, *params):
-        text_ids = model._pending_text_ids
-        model._pending_text_ids = None
-        out = model.engine.forward(wave, dec_ids, labels, training=training, text_ids=text_ids)
+        text_ids, prompt_ids = model._pending_text_ids, model._pending_prompt_ids
+        model._pending_text_ids = model._pending_prompt_ids = None
+        out = model.engine.forward(wave, dec_ids, labels, training=training, text_ids=text_ids, prompt_ids=prompt_ids,
+                                   weighted_sum=model.weighted_sum)
         ctx.model = model
         ctx.n_params = len(params)
         model._last = out
@@ -195,6 +196,7 @@ class SpeechMixEED(nn.Module):
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         self._last = None
         self._pending_text_ids = None
+        self._pending_prompt_ids = None
         self.store = None
         self.engine = None
         if self.device.type == "cuda":
@@ -329,10 +331,14 @@ class SpeechMixEED(nn.Module):
             decoder_input_ids = handle_decoder_input_none(lc, len(wave), device=self.device)
         elif decoder_input_ids is None and labels is not None:
             decoder_input_ids = shift_tokens_right(labels.to(self.device), lc.pad_token_id, lc.decoder_start_token_id)
-        if self.weighted_sum:
-            raise NotImplementedError("weighted_sum=True is not implemented in the HIP engine yet (off in all baseline configs)")
+        prompt_ids = None
         if input_text_prompt is not None:
-            raise NotImplementedError("input_text_prompt is not implemented in the HIP engine yet")
+            if torch.is_tensor(input_text_prompt):          # extension: already-tokenised prompt
+                prompt_ids = input_text_prompt.reshape(-1).to(self.device)
+            else:
+                if self.tokenizer is None:
+                    raise RuntimeError("input_text_prompt needs a tokenizer (construct with a local nlp_model_config directory)")
+                prompt_ids = self.tokenizer(input_text_prompt, return_tensors="pt")["input_ids"].reshape(-1).to(self.device)
         dec = decoder_input_ids.to(self.device).contiguous()
         lab = labels.to(self.device).contiguous() if labels is not None else None
         training = self.training and self.encoder_model.training
@@ -341,11 +347,12 @@ class SpeechMixEED(nn.Module):
         text = text_input_ids.to(self.device).contiguous() if (text_input_ids is not None and self._uses_text_ids) else None
         if want_grad:
             params = tuple(self.store.params.values()) if self.autograd_param_inputs else ()
-            self._pending_text_ids = text
+            self._pending_text_ids, self._pending_prompt_ids = text, prompt_ids
             loss = _StepFn.apply(self, wave, dec, lab, training, self._anchor, *params)
             out = self._last
         else:
-            out = self.engine.forward(wave, dec, lab, training=False, text_ids=text)
+            out = self.engine.forward(wave, dec, lab, training=False, text_ids=text, prompt_ids=prompt_ids,
+                                      weighted_sum=self.weighted_sum)
             loss = out["loss"].view(()) if out["loss"] is not None else None
             self.engine.saved = None
         B, Ld = dec.shape
@@ -361,6 +368,8 @@ class SpeechMixEED(nn.Module):
             return_dict["encoder_last_hidden_state"] = out["enc_last"].view(B, T, d).float()
             return_dict["inputs_embeds"] = out["inputs_embeds"].view(B, S, dd).float()
             return_dict["lm_encoder_last_hidden"] = out["lm_enc_last"].view(B, S, dd).float()
+            if out.get("sw") is not None:
+                return_dict["weighted_sum"] = out["sw"]
             for k, v in out.get("parts", {}).items():
                 return_dict[k + "_loss"] = v.view(())
         return_dict["logits"] = out["argmax"]

@@ -282,3 +282,27 @@ def mse(a, b, loss, da, n, gscale=1.0):
 def add_f32_into(src, dst, n, dtype):
     L.check(L.lib().smx_add_f32_into(C.c_void_p(_ptr(src)), C.c_void_p(_ptr(dst)), C.c_longlong(n), dtype, _stream()),
             "smx_add_f32_into")
+
+
+def _wsum_params(hidden, w, out, dy, dots, dw, sw, n):
+    p = L.WsumParams()
+    for i, h in enumerate(hidden):
+        p.h[i] = _ptr(h)
+    p.w, p.out, p.dy, p.dots, p.dw, p.sw, p.n, p.L1 = _ptr(w), _ptr(out), _ptr(dy), _ptr(dots), _ptr(dw), _ptr(sw), n, \
+        len(hidden)
+    return p
+
+
+def weighted_sum_fwd(hidden, w, out, sw, n, dtype):
+    p = _wsum_params(hidden, w, out, None, None, None, sw, n)
+    L.check(L.lib().smx_weighted_sum_fwd(C.byref(p), dtype, _stream()), "smx_weighted_sum_fwd")
+
+
+def weighted_sum_bwd(hidden, w, dy, dots, dw, sw, n, dtype):
+    p = _wsum_params(hidden, w, None, dy, dots, dw, sw, n)
+    L.check(L.lib().smx_weighted_sum_bwd(C.byref(p), dtype, _stream()), "smx_weighted_sum_bwd")
+
+
+def axpy_dev(y, x, a, idx, n, init, dtype):
+    L.check(L.lib().smx_axpy_dev(C.c_void_p(_ptr(y)), C.c_void_p(_ptr(x)), C.c_void_p(_ptr(a)), idx, C.c_longlong(n),
+                                 int(init), dtype, _stream()), "smx_axpy_dev")

@@ -53,7 +53,7 @@ class StepRunner:
         self.store.external_updates = False          # this runner keeps the bf16 compute copies fresh itself
         self.store.refresh_shadow(force=True)
 
-    def step(self, input_values, labels, decoder_input_ids=None):
+    def step(self, input_values, labels, decoder_input_ids=None, text_input_ids=None):
         """One optimizer step on this rank's shard.  Returns the (device) loss tensor of this rank."""
         from .model import shift_tokens_right
         m, eng, st = self.model, self.engine, self.store
@@ -63,7 +63,9 @@ class StepRunner:
         if decoder_input_ids is None:
             decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
         self.reducer.begin_step()
-        out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(), training=m.training)
+        text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
+        out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(), training=m.training, text_ids=text,
+                          weighted_sum=m.weighted_sum)
         eng.backward(gscale=1.0, zero_grads=True)
         self.reducer.finish()
         self.t += 1

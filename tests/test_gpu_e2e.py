@@ -139,3 +139,55 @@ def test_speechmix_self_t5_losses_and_grads(dtype, tol, tol_grad):
     o2 = model.cal_loss(inputs_embeds=gold["inputs_embeds"], text_input_ids=inp["text_input_ids"], decoder_input_ids=dec_in,
                         labels=inp["labels"])
     assert abs(o2["loss"].item() - gold["loss"].item()) < tol
+
+
+def test_weighted_sum_share_ratio_matches_reference_and_oracle_grads():
+    """weighted_sum=True (HF-twin semantics: L+1 softmax weights), share_layer_ratio 0.5, ds 4, no labels -> logits
+    vs the reference fixture; then with labels: loss and gradients (incl. weights_sum) vs the CPU oracle."""
+    from oracle import speechmix_oracle as O
+    from speechmix_amd.model import SpeechMixEED
+    sd, inp, gold, m = load_case("eed_w2v2_bart_ws")
+    model = SpeechMixEED(m["enc_cfg"], m["lm_cfg"], share_layer_ratio=0.5, down_scale=4, weighted_sum=True,
+                         compute_dtype="fp32").eval()
+    assert model.load_state_dict(sd, strict=False).missing_keys == []
+    with torch.no_grad():
+        out = model(inp["input_values"], return_model_detail=True)
+    assert _err(out["raw_logits"], gold["raw_logits"]) < 1e-4
+    assert torch.equal(out["logits"].cpu(), gold["logits"])
+    assert abs(out["weighted_sum"].sum().item() - 1.0) < 1e-5 and out["weighted_sum"].numel() == 3
+    labels = torch.randint(4, 128, (2, 5))
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()
+              if not k.endswith(("embed_tokens.weight", "lm_head.weight", "nlp_emb.weight"))}
+    ref = O.speechmix_eed_forward(leaves, m["enc_cfg"], m["lm_cfg"], inp["input_values"], labels=labels, down_scale=4,
+                                  weighted_sum=True, num_speech_layers=2)
+    ref["loss"].backward()
+    out = model(inp["input_values"], labels=labels)
+    assert abs(out["loss"].item() - ref["loss"].item()) < 1e-4
+    out["loss"].backward()
+    named = dict(model.named_parameters())
+    for name in ("weights_sum", "enc_to_dec_proj.weight", "encoder_model.encoder.layers.0.attention.q_proj.weight",
+                 "encoder_model.feature_projection.projection.weight"):
+        g = leaves[name].grad
+        e = _err(named[name].grad, g)
+        assert e <= 2e-3 * max(g.abs().max().item(), 1e-3), (name, e)
+
+
+def test_text_prompt_prepended_like_reference():
+    """input_text_prompt (ref:speechmix/model.py:168-171): prompt token embeddings prepended to the speech embeddings."""
+    from oracle import speechmix_oracle as O
+    model, inp, gold, m = _build("eed_w2v2_bart", "fp32")
+    sd, _, _, _ = load_case("eed_w2v2_bart")
+    prompt = torch.tensor([7, 9, 11])
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()
+              if not k.endswith(("embed_tokens.weight", "lm_head.weight", "nlp_emb.weight"))}
+    ref = O.speechmix_eed_forward(leaves, m["enc_cfg"], m["lm_cfg"], inp["input_values"], labels=inp["labels"], down_scale=2,
+                                  prompt_ids=prompt[None])
+    ref["loss"].backward()
+    out = model(inp["input_values"], labels=inp["labels"], input_text_prompt=prompt, return_model_detail=True)
+    assert _err(out["raw_logits"], ref["raw_logits"]) < 1e-4
+    assert abs(out["loss"].item() - ref["loss"].item()) < 1e-5
+    out["loss"].backward()
+    g = leaves["decoder_model.model.shared.weight"].grad
+    assert _err(model.decoder_model.model.shared.weight.grad, g) <= 2e-3 * g.abs().max().item()
+    g = leaves["enc_to_dec_proj.weight"].grad
+    assert _err(model.enc_to_dec_proj.weight.grad, g) <= 2e-3 * g.abs().max().item()
