@@ -37,6 +37,7 @@ typedef struct SmxGemmParams {
     SmxRowView a, b, c, e;
     long long batch_a, batch_b, batch_c, batch_bias, batch_e;
     int M, N, K, a_rc, b_rc, act, out_f32, atomic, nbatch, split_k, tr_mode; float alpha; long long split_stride;
+    float drop_p; unsigned drop_seed;   /* dropout after the activation, before the residual (see "dropout" below) */
 } SmxGemmParams;
 int smx_gemm(const SmxGemmParams* p, int dtype, hipStream_t stream);
 int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stride, float* dst, int accumulate, hipStream_t stream);
@@ -46,11 +47,11 @@ int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stri
  * TF:models/t5/modeling_t5.py:50-72. */
 typedef struct SmxNormParams {
     const void *x, *pos; void *xsum_out, *y; const float *gamma, *beta; float *mean, *rstd;
-    int M, D, pos_period, pos_offset, rms, act; float eps;
+    int M, D, pos_period, pos_offset, rms, act; float eps; float drop_p; unsigned drop_seed;
 } SmxNormParams;
 typedef struct SmxNormBwdParams {
     const void *dy, *x, *dres; void* dx; const float *gamma, *beta, *mean, *rstd; float *dgamma, *dbeta, *dpos, *partials;
-    int M, D, pos_period, pos_offset, rms, act;
+    int M, D, pos_period, pos_offset, rms, act; float drop_p; unsigned drop_seed;
 } SmxNormBwdParams;
 int smx_norm_fwd(const SmxNormParams* p, int dtype, hipStream_t stream);
 int smx_norm_bwd(const SmxNormBwdParams* p, int dtype, hipStream_t stream);
@@ -61,7 +62,7 @@ int smx_norm_bwd(const SmxNormBwdParams* p, int dtype, hipStream_t stream);
 typedef struct SmxAttnParams {
     const void *Q, *K, *V; void* O; float* lse; const float* bias; const void* dO; void *dQ, *dK, *dV; float *delta, *dbias;
     long long q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, do_bs, do_ld;
-    int B, H, Tq, Tk, D, causal; float scale;
+    int B, H, Tq, Tk, D, causal; float scale; float drop_p; unsigned drop_seed;
 } SmxAttnParams;
 int smx_attention_fwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
 int smx_attention_bwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
@@ -109,6 +110,21 @@ int smx_softmax_rows_bwd(const float* p, const float* dp, float* dx, int R, int 
 int smx_mse(const float* a, const float* b, float* loss, float* da, long long n, float gscale, hipStream_t stream);
 int smx_add_f32_into(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 
+/* dropout (nn.functional.dropout at TF:models/wav2vec2/modeling_wav2vec2.py:433,545,569,634,703; TF:models/bart/
+ * modeling_bart.py:233,331,367-369,829,1064; TF:models/t5/modeling_t5.py:112,147,333,1020,1102).  Counter based: the
+ * keep decision of element i at a site is hash32(seed, i) >> 8 >= p * 2^24, kept values are scaled by 1/(1-p); the
+ * fused sites (GEMM epilogue, norm output, attention probabilities) and this stand-alone kernel use the same function,
+ * so a backward pass regenerates the forward mask from (p, seed) instead of storing it. */
+int smx_dropout(const void* x, void* out, long long n, float p, unsigned seed, int dtype, hipStream_t stream);
+
+/* layer-weighted sum of the L+1 encoder hidden states (ref:speechmix/hf_model.py:411-423; ref:speechmix/model.py:150-157) */
+typedef struct SmxWsumParams {
+    const void* h[40]; const float* w; void* out; const void* dy; float *dots, *dw, *sw; long long n; int L1;
+} SmxWsumParams;
+int smx_weighted_sum_fwd(const SmxWsumParams* p, int dtype, hipStream_t stream);
+int smx_weighted_sum_bwd(const SmxWsumParams* p, int dtype, hipStream_t stream);
+int smx_axpy_dev(void* y, const void* x, const float* a, int idx, long long n, int init, int dtype, hipStream_t stream);
+
 /* flat-buffer optimizer step (what HF Trainer's clip + optimizer.step do per tensor, ref:train.py:291-330) */
 typedef struct SmxOptParams {
     float* p; const float* g; float *m, *v; void* shadow; const float* gnorm_sq; long long n;
@@ -125,6 +141,7 @@ int smx_sizeof_SmxAttnParams(void);
 int smx_sizeof_SmxConv0Params(void);
 int smx_sizeof_SmxCEParams(void);
 int smx_sizeof_SmxOptParams(void);
+int smx_sizeof_SmxWsumParams(void);
 
 #ifdef __cplusplus
 }

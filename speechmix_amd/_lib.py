@@ -29,7 +29,7 @@ class GemmParams(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("a_rc", C.c_int), ("b_rc", C.c_int),
                 ("act", C.c_int), ("out_f32", C.c_int), ("atomic", C.c_int), ("nbatch", C.c_int),
                 ("split_k", C.c_int), ("tr_mode", C.c_int), ("alpha", C.c_float),
-                ("split_stride", C.c_longlong)]
+                ("split_stride", C.c_longlong), ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
 
 
 _lib = None
@@ -55,7 +55,7 @@ class NormParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("pos", C.c_void_p), ("xsum_out", C.c_void_p), ("y", C.c_void_p),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
-                ("rms", C.c_int), ("act", C.c_int), ("eps", C.c_float)]
+                ("rms", C.c_int), ("act", C.c_int), ("eps", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
 
 
 class NormBwdParams(C.Structure):
@@ -63,7 +63,7 @@ class NormBwdParams(C.Structure):
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dpos", C.c_void_p), ("partials", C.c_void_p),
                 ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
-                ("rms", C.c_int), ("act", C.c_int)]
+                ("rms", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
 
 
 class AttnParams(C.Structure):
@@ -75,7 +75,7 @@ class AttnParams(C.Structure):
                 ("dq_bs", C.c_longlong), ("dq_ld", C.c_longlong), ("dk_bs", C.c_longlong), ("dk_ld", C.c_longlong),
                 ("dv_bs", C.c_longlong), ("dv_ld", C.c_longlong), ("do_bs", C.c_longlong), ("do_ld", C.c_longlong),
                 ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("D", C.c_int),
-                ("causal", C.c_int), ("scale", C.c_float)]
+                ("causal", C.c_int), ("scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
 
 
 class Conv0Params(C.Structure):

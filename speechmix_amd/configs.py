@@ -170,7 +170,9 @@ def _from_hf_dict(d: dict, kind: str):
                   encoder_attention_heads=d["num_heads"], decoder_attention_heads=d["num_heads"],
                   encoder_ffn_dim=d["d_ff"], decoder_ffn_dim=d["d_ff"],
                   activation_function=d.get("dense_act_fn", "relu"), is_gated_act=d.get("is_gated_act", False),
-                  tie_word_embeddings=d.get("tie_word_embeddings", True), scale_embedding=False)
+                  tie_word_embeddings=d.get("tie_word_embeddings", True), scale_embedding=False,
+                  dropout=d.get("dropout_rate", 0.1), attention_dropout=d.get("dropout_rate", 0.1),
+                  activation_dropout=d.get("dropout_rate", 0.1))
     return LMConfig(**kw)
 
 

@@ -27,7 +27,12 @@ struct SmxAttnParams {
     int B, H, Tq, Tk, D;
     int causal;
     float scale;
+    float drop_p;         // dropout on the attention probabilities (0: off); mask index = ((b*H+h)*Tq+q)*Tk+key
+    unsigned drop_seed;
 };
+#define ATT_DROP(p, b, h, q, k) \
+    smx_drop_mul((p).drop_seed, (unsigned)((((long long)(b) * (p).H + (h)) * (p).Tq + (q)) * (p).Tk + (k)), smx_thresh24((p).drop_p), \
+                 1.0f / (1.0f - (p).drop_p))
 
 #define NEG_BIG (-1e30f)
 
@@ -53,7 +58,8 @@ __global__ void attn_fwd_simple(SmxAttnParams p) {
         const float mn = fmaxf(m, s);
         const float a = expf(m - mn), e = expf(s - mn);
         l = l * a + e;
-        for (int d = 0; d < p.D; ++d) o[d] = o[d] * a + e * Cvt<T>::ld(V + k * p.v_ld + d);
+        const float ed = p.drop_p > 0.f ? e * ATT_DROP(p, b, h, q, k) : e;
+        for (int d = 0; d < p.D; ++d) o[d] = o[d] * a + ed * Cvt<T>::ld(V + k * p.v_ld + d);
         m = mn;
     }
     T* O = reinterpret_cast<T*>(p.O) + b * p.o_bs + q * p.o_ld + h * p.D;
@@ -101,6 +107,7 @@ __global__ void attn_bwd_dq_simple(SmxAttnParams p) {
         }
         s *= p.scale;
         if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
+        if (p.drop_p > 0.f) dp *= ATT_DROP(p, b, h, q, k);
         const float ds = expf(s - lse) * (dp - delta);
         if (p.dbias) atomicAdd(p.dbias + ((long long)h * p.Tq + q) * p.Tk + k, ds);
         for (int d = 0; d < p.D; ++d) dq[d] = fmaf(ds * p.scale, Cvt<T>::ld(K + k * p.k_ld + d), dq[d]);
@@ -131,9 +138,10 @@ __global__ void attn_bwd_dkv_simple(SmxAttnParams p) {
         if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
         const long long li = ((long long)b * p.H + h) * p.Tq + q;
         const float pr = expf(s - p.lse[li]);
-        const float ds = pr * (dp - p.delta[li]) * p.scale;
+        const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, q, k) : 1.f;
+        const float ds = pr * (dm * dp - p.delta[li]) * p.scale;
         for (int d = 0; d < p.D; ++d) {
-            dv[d] = fmaf(pr, Cvt<T>::ld(dO + q * p.do_ld + d), dv[d]);
+            dv[d] = fmaf(pr * dm, Cvt<T>::ld(dO + q * p.do_ld + d), dv[d]);
             dk[d] = fmaf(ds, Cvt<T>::ld(Q + q * p.q_ld + d), dk[d]);
         }
     }
@@ -252,8 +260,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(SmxAttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = __expf(s[t][r] - mn);
-                s[t][r] = e;
                 rs += e;
+                s[t][r] = p.drop_p > 0.f ? e * ATT_DROP(p, b, h, q, k0 + t * 16 + 4 * g + r) : e;
             }
         l = l * alpha + group_sum(rs);
         m = mn;
@@ -333,7 +341,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16(SmxAttnParams p) {
                 if (p.bias && q < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + q) * p.Tk + key];
                 float pr = __expf(v - lse);
                 if (key >= p.Tk || q >= p.Tq || (p.causal && key > q + coff)) pr = 0.f;
-                ds[t][r] = pr * (dp[r] - delta);
+                const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, q, key) : 1.f;
+                ds[t][r] = pr * (dm * dp[r] - delta);
             }
         }
 #pragma unroll
@@ -413,8 +422,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(SmxAttnParams p) {
                 if (p.bias && qq < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + qq) * p.Tk + key];
                 float pr = __expf(v - sLse[ql]);
                 if (qq >= p.Tq || key >= p.Tk || (p.causal && key > qq + coff)) pr = 0.f;
-                pt[t][r] = pr;
-                ds[t][r] = pr * (dp[r] - sDelta[ql]);
+                const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, qq, key) : 1.f;
+                pt[t][r] = pr * dm;
+                ds[t][r] = pr * (dm * dp[r] - sDelta[ql]);
             }
         }
 #pragma unroll

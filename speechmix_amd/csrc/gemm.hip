@@ -37,6 +37,8 @@ struct SmxGemmParams {
     int tr_mode;            // 1: LDS-DMA kernel (production), 2: register-staged + tr reads, 0: 16-bit LDS reads (debug)
     float alpha;
     long long split_stride; // elements between split-K slabs (atomic == 0)
+    float drop_p;           // dropout applied after the activation and before the residual add (0: off); in the
+    unsigned drop_seed;     // aux_in (backward-through-activation) mode it multiplies by the same forward mask
 };
 
 #define BM 128
@@ -151,6 +153,9 @@ __device__ __forceinline__ void epilogue4(const SmxGemmParams& p, long long zc, 
             if (p.aux_out) reinterpret_cast<bf16_t*>(p.aux_out)[sb + j] = f2bf(x);
             if (!p.aux_in) x = act_fwd(x, p.act);
             else x *= act_grad(bf2f(reinterpret_cast<const bf16_t*>(p.aux_in)[sb + j]), p.act);
+            if (p.drop_p > 0.f)
+                x *= smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n0 + j + zc), smx_thresh24(p.drop_p),
+                                  1.0f / (1.0f - p.drop_p));
             if (p.resid) x += bf2f(reinterpret_cast<const bf16_t*>(p.resid)[sb + j]);
             v[j] = x;
         }
@@ -920,6 +925,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
             if (p.aux_out) reinterpret_cast<float*>(p.aux_out)[rowe + n] = x;
             if (!p.aux_in) x = act_fwd(x, p.act);
             else x *= act_grad(reinterpret_cast<const float*>(p.aux_in)[rowe + n], p.act);
+            if (p.drop_p > 0.f)
+                x *= smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), smx_thresh24(p.drop_p),
+                                  1.0f / (1.0f - p.drop_p));
             if (p.resid) x += reinterpret_cast<const float*>(p.resid)[rowe + n];
             float* c = reinterpret_cast<float*>(p.C) + rowb + n;
             if (p.atomic == 1) atomicAdd(c, x); else if (p.atomic == 2) *c += x; else *c = x;

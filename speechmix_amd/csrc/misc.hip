@@ -580,3 +580,34 @@ extern "C" int smx_axpy_dev(void* y, const void* x, const float* a, int idx, lon
     else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------- out = x * dropout_mask(seed) (elementwise, flat index)
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long long n, float p, unsigned seed) {
+    const unsigned th = smx_thresh24(p);
+    const float inv = 1.0f / (1.0f - p);
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long step = (long long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += step) {
+        float v[8];
+        load8(x + i, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= smx_drop_mul(seed, (unsigned)(i + e), th, inv);
+        store8(out + i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {      // ragged tail (only odd-sized test tensors get here)
+        const long long t = (n & ~7ll) + threadIdx.x;
+        Cvt<T>::st(out + t, Cvt<T>::ld(x + t) * smx_drop_mul(seed, (unsigned)t, th, inv));
+    }
+}
+extern "C" int smx_dropout(const void* x, void* out, long long n, float p, unsigned seed, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0 || p < 0.f || p >= 1.f) return SMX_EINVAL;
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, n, p, seed);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)out, n, p, seed);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}

@@ -25,6 +25,8 @@ struct SmxNormParams {
     int rms;              // 1: RMS norm
     int act;              // activation applied after affine
     float eps;
+    float drop_p;         // dropout on the output (0: off); mask index = row * D + column
+    unsigned drop_seed;
 };
 
 template <typename T>
@@ -88,7 +90,10 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(SmxNormParams p) {
             for (int e = 0; e < 8; ++e) {
                 float t = (v[j][e] - mean) * rstd * gm[e];
                 if (p.beta) t += bt[e];
-                o[e] = act_fwd(t, p.act);
+                t = act_fwd(t, p.act);
+                if (p.drop_p > 0.f)
+                    t *= smx_drop_mul(p.drop_seed, (unsigned)(row * p.D + c + e), smx_thresh24(p.drop_p), 1.0f / (1.0f - p.drop_p));
+                o[e] = t;
             }
             store8(y + c, o);
         }
@@ -111,6 +116,8 @@ struct SmxNormBwdParams {
     int M, D;
     int pos_period, pos_offset;
     int rms, act;
+    float drop_p;         // the forward output was dropped: dy is multiplied by the same mask on load
+    unsigned drop_seed;
 };
 
 // Backward is two kernels: (1) dx, one wave per row at full occupancy (like the forward); (2) the gamma/beta
@@ -148,6 +155,8 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(SmxNormBwdParams p) {
             for (int e = 0; e < 8; ++e) {
                 const float xhat = (xv[e] - mean) * rstd;
                 float d = dv[e];
+                if (p.drop_p > 0.f)
+                    d *= smx_drop_mul(p.drop_seed, (unsigned)(row * p.D + c + e), smx_thresh24(p.drop_p), 1.0f / (1.0f - p.drop_p));
                 if (ACT) d *= act_grad(xhat * gm[e] + bt[e], p.act);
                 const float gg = d * gm[e];
                 xh[j][e] = xhat;
@@ -225,6 +234,9 @@ __global__ __launch_bounds__(256) void norm_bwd_param_kernel(SmxNormBwdParams p)
             for (int e = 0; e < 8; ++e) {
                 const float xhat = (xv[r][j][e] - mean[r]) * rstd[r];
                 float d = dv[r][j][e];
+                if (p.drop_p > 0.f)
+                    d *= smx_drop_mul(p.drop_seed, (unsigned)((row0 + r) * p.D + (lane + 64 * j) * 8 + e), smx_thresh24(p.drop_p),
+                                      1.0f / (1.0f - p.drop_p));
                 if (ACT) d *= act_grad(xhat * gm[j][e] + bt[j][e], p.act);
                 dg[j][e] += d * xhat;
                 db[j][e] += d;

@@ -98,6 +98,21 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     return 1.f;
 }
 
+// ---- counter-based dropout: keep(idx) is a pure function of (seed, element index), so backward regenerates
+// the forward mask instead of storing it (TF: nn.functional.dropout sites listed in engine.py) ----
+__device__ __forceinline__ unsigned smx_hash32(unsigned seed, unsigned idx) {
+    unsigned x = idx * 0x9E3779B1u + seed;
+    x ^= x >> 15; x *= 0x85EBCA77u;
+    x ^= x >> 13; x *= 0xC2B2AE3Du;
+    x ^= x >> 16;
+    return x;
+}
+// returns the multiplier: 0 (dropped) or 1/(1-p) (kept)
+__device__ __forceinline__ float smx_drop_mul(unsigned seed, unsigned idx, unsigned thresh24, float inv_keep) {
+    return (smx_hash32(seed, idx) >> 8) >= thresh24 ? inv_keep : 0.f;
+}
+__host__ __device__ __forceinline__ unsigned smx_thresh24(float p) { return (unsigned)(p * 16777216.0f); }
+
 // ---- wave / block reductions (64-wide) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

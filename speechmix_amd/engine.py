@@ -46,7 +46,20 @@ class Engine:
         self._persist: Dict[str, torch.Tensor] = {}
         self.saved = None
         self.rng = np.random.default_rng(0)
+        self.drop_rng = np.random.default_rng(0x5eed)   # per-site dropout seeds (masks are regenerated in backward)
         self.stage_cb = None      # callable(stage_name): gradient ranges of that stage are final (dist.GradReducer)
+
+    def _dp(self, p):
+        """(p, fresh 32-bit seed) for one dropout site, or None when the site is inactive."""
+        return (float(p), int(self.drop_rng.integers(1, 2 ** 32 - 1))) if p and p > 0 else None
+
+    def _dropped(self, dy, drop, n):
+        """dy * (the forward mask of a dropout site): gradient entering the dropped branch."""
+        if drop is None:
+            return dy
+        out = torch.empty_like(dy)
+        ops.dropout(dy, out, n, drop[0], drop[1], self.dt)
+        return out
 
     def _stage(self, name):
         if self.stage_cb is not None:
@@ -126,27 +139,27 @@ class Engine:
             ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha)
 
     def ln_fwd(self, x, wname, bname, M, D, eps, rms=False, act=ACT_NONE, pos=None, pos_period=0, pos_offset=0,
-               want_sum=False):
+               want_sum=False, drop=None):
         y = self.new(M, D)
         mean = None if rms else self.new(M, dt=torch.float32)
         rstd = self.new(M, dt=torch.float32)
         xs = self.new(M, D) if want_sum else None
         ops.norm_fwd(x, y, self.P(wname), self.P(bname) if bname else None, mean, rstd, M, D, self.dt, eps=eps, rms=rms,
-                     act=act, pos=pos, pos_period=pos_period, pos_offset=pos_offset, xsum_out=xs)
-        return y, (xs if want_sum else x, mean, rstd)
+                     act=act, pos=pos, pos_period=pos_period, pos_offset=pos_offset, xsum_out=xs, drop=drop)
+        return y, (xs if want_sum else x, mean, rstd, drop)
 
     def ln_bwd(self, dy, saved, wname, bname, M, D, rms=False, act=ACT_NONE, dres=None, dpos=None, pos_period=0,
                pos_offset=0, dx=None):
-        x, mean, rstd = saved
+        x, mean, rstd, drop = saved
         dx = dx if dx is not None else self.new(M, D)
         train = self.tr(wname)
         ops.norm_bwd(dy, x, dx, self.P(wname), self.P(bname) if bname else None, mean, rstd,
                      self.G(wname) if train else None, self.G(bname) if (bname and train) else None, M, D, self.dt,
-                     rms=rms, act=act, dres=dres, dpos=dpos, pos_period=pos_period, pos_offset=pos_offset)
+                     rms=rms, act=act, dres=dres, dpos=dpos, pos_period=pos_period, pos_offset=pos_offset, drop=drop)
         return dx
 
     # ------------------------------------------------------------------ attention block (self or cross)
-    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None):
+    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None, drop=None):
         """names: dict(q,k,v,o -> (weight, bias|None)).  Returns (o [B*Tq, d], saved)."""
         Mq, Mk = B * Tq, B * Tk
         hd = d // H
@@ -156,7 +169,7 @@ class Engine:
             wqkv = self.st.cat([qn[0], kn[0], vn[0]])
             bqkv = self.st.cat([qn[1], kn[1], vn[1]], "p32") if qn[1] else None
             qkv = self.lin(x, wqkv, bqkv, Mq, 3 * d, d)
-            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop)
             desc.set("Q", qkv, 0, Tq * 3 * d, 3 * d)
             desc.set("K", qkv, d, Tk * 3 * d, 3 * d)
             desc.set("V", qkv, 2 * d, Tk * 3 * d, 3 * d)
@@ -166,7 +179,7 @@ class Engine:
             wkv = self.st.cat([kn[0], vn[0]])
             bkv = self.st.cat([kn[1], vn[1]], "p32") if kn[1] else None
             kv = self.lin(kvsrc, wkv, bkv, Mk, 2 * d, d)
-            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop)
             desc.set("Q", qkv, 0, Tq * d, d)
             desc.set("K", kv, 0, Tk * 2 * d, 2 * d)
             desc.set("V", kv, d, Tk * 2 * d, 2 * d)
@@ -217,19 +230,21 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ transformer layers
-    def _ffn_fwd(self, h, M, d, F, n1, n2, act, resid):
+    def _ffn_fwd(self, h, M, d, F, n1, n2, act, resid, d_act=None, d_out=None):
+        """resid + drop_out(fc2(drop_act(act(fc1(h)))))  - both dropouts run inside the GEMM epilogues."""
         pre = self.new(M, F)
-        f = self.lin(h, self.W(n1[0]), self.P(n1[1]) if n1[1] else None, M, F, d, act=act, aux_out=pre)
-        y = self.lin(f, self.W(n2[0]), self.P(n2[1]) if n2[1] else None, M, d, F, resid=resid)
-        return y, (h, pre, f)
+        f = self.lin(h, self.W(n1[0]), self.P(n1[1]) if n1[1] else None, M, F, d, act=act, aux_out=pre, drop=d_act)
+        y = self.lin(f, self.W(n2[0]), self.P(n2[1]) if n2[1] else None, M, d, F, resid=resid, drop=d_out)
+        return y, (h, pre, f, d_act, d_out)
 
     def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid):
         """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid)."""
-        h, pre, f = sv
+        h, pre, f, d_act, d_out = sv
+        dy = self._dropped(dy, d_out, M * d)
         if self.tr(n2[0]):
             self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=self.G(n2[1]) if n2[1] else None)
         dpre = self.new(M, F)
-        self.dgrad(dy, self.W(n2[0]), dpre, M, d, F, aux_in=pre, act=act)
+        self.dgrad(dy, self.W(n2[0]), dpre, M, d, F, aux_in=pre, act=act, drop=d_act)
         if self.tr(n1[0]):
             self.wgrad(dpre, h, self.G(n1[0]), M, F, d, gb=self.G(n1[1]) if n1[1] else None)
         dh = self.new(M, d)
@@ -237,40 +252,50 @@ class Engine:
         return dh
 
     def layer_fwd(self, x, B, T, d, H, F, nm, pre_ln, act, eps, causal=False, scale=None, enc=None, Tk=None, rms=False,
-                  bias=None, cross_bias=None):
-        """One transformer layer.  nm: dict with keys attn{q,k,v,o}, ln1, [xattn, lnx], fc1, fc2, ln2."""
+                  bias=None, cross_bias=None, drop=None):
+        """One transformer layer.  nm: dict with keys attn{q,k,v,o}, ln1, [xattn, lnx], fc1, fc2, ln2.
+        drop = (hidden p, attention-probability p, activation p) in training mode, else None.  Sites (identical in
+        TF:models/wav2vec2/modeling_wav2vec2.py:575-654, TF:models/bart/modeling_bart.py:260-475, T5 blocks): the
+        attention probabilities, the out_proj output, the activation, the fc2 output."""
         M = B * T
         scale = scale if scale is not None else (d // H) ** -0.5
         sv = {}
+        ph, pa, pf = drop if drop is not None else (0.0, 0.0, 0.0)
+        sv["d_o"], sv["d_xo"] = self._dp(ph), (self._dp(ph) if enc is not None else None)
+        d_act, d_out = self._dp(pf), self._dp(ph)
+        da, dxa = self._dp(pa), (self._dp(pa) if enc is not None else None)
         if not pre_ln:
-            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias)
-            s1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x)
+            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da)
+            s1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x, drop=sv["d_o"])
             h, sv["ln1"] = self.ln_fwd(s1, nm["ln1"][0], nm["ln1"][1], M, d, eps)
             if enc is not None:
-                o2, sv["x"] = self.attn_fwd(h, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias)
-                s2 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=h)
+                o2, sv["x"] = self.attn_fwd(h, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias, drop=dxa)
+                s2 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=h,
+                              drop=sv["d_xo"])
                 h, sv["lnx"] = self.ln_fwd(s2, nm["lnx"][0], nm["lnx"][1], M, d, eps)
-            s3, sv["f"] = self._ffn_fwd(h, M, d, F, nm["fc1"], nm["fc2"], act, h)
+            s3, sv["f"] = self._ffn_fwd(h, M, d, F, nm["fc1"], nm["fc2"], act, h, d_act, d_out)
             y, sv["ln2"] = self.ln_fwd(s3, nm["ln2"][0], nm["ln2"][1], M, d, eps)
         else:
             n1, sv["ln1"] = self.ln_fwd(x, nm["ln1"][0], nm["ln1"][1], M, d, eps, rms=rms)
-            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias)
-            x1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x)
+            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da)
+            x1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x, drop=sv["d_o"])
             if enc is not None:
                 nx, sv["lnx"] = self.ln_fwd(x1, nm["lnx"][0], nm["lnx"][1], M, d, eps, rms=rms)
-                o2, sv["x"] = self.attn_fwd(nx, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias)
-                x1 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=x1)
+                o2, sv["x"] = self.attn_fwd(nx, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias, drop=dxa)
+                x1 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=x1,
+                              drop=sv["d_xo"])
             n2, sv["ln2"] = self.ln_fwd(x1, nm["ln2"][0], nm["ln2"][1], M, d, eps, rms=rms)
-            y, sv["f"] = self._ffn_fwd(n2, M, d, F, nm["fc1"], nm["fc2"], act, x1)
+            y, sv["f"] = self._ffn_fwd(n2, M, d, F, nm["fc1"], nm["fc2"], act, x1, d_act, d_out)
         sv["dims"] = (B, T, d, H, F)
         return y, sv
 
     def _b(self, n):
         return self.P(n) if n else None
 
-    def _oproj_bwd(self, dy, sv_attn, names, M, d):
-        """dy: grad wrt out_proj output; returns grad wrt attention output o."""
+    def _oproj_bwd(self, dy, sv_attn, names, M, d, drop=None):
+        """dy: grad wrt the (dropped) out_proj output; returns grad wrt attention output o."""
         wn, bn = names["o"]
+        dy = self._dropped(dy, drop, M * d)
         if self.tr(wn):
             self.wgrad(dy, sv_attn["o"], self.G(wn), M, d, d, gb=self.G(bn) if bn else None)
         do = self.new(M, d)
@@ -285,19 +310,19 @@ class Engine:
             dh = self._ffn_bwd(ds3, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, ds3)
             if "x" in sv:
                 ds2 = self.ln_bwd(dh, sv["lnx"], nm["lnx"][0], nm["lnx"][1], M, d)
-                do2 = self._oproj_bwd(ds2, sv["x"], nm["xattn"], M, d)
+                do2 = self._oproj_bwd(ds2, sv["x"], nm["xattn"], M, d, sv["d_xo"])
                 dh = self.attn_bwd(do2, sv["x"], nm["xattn"], dx_resid=ds2, dkv_accum=denc)
             ds1 = self.ln_bwd(dh, sv["ln1"], nm["ln1"][0], nm["ln1"][1], M, d)
-            do = self._oproj_bwd(ds1, sv["a"], nm["attn"], M, d)
+            do = self._oproj_bwd(ds1, sv["a"], nm["attn"], M, d, sv["d_o"])
             return self.attn_bwd(do, sv["a"], nm["attn"], dx_resid=ds1)
         # pre-LN: y = x1 + ffn(LN2(x1)); x1 = x(+cross) + attn(LN1(x))
         dn2 = self._ffn_bwd(dy, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, None)
         dx1 = self.ln_bwd(dn2, sv["ln2"], nm["ln2"][0], nm["ln2"][1] if not rms else None, M, d, rms=rms, dres=dy)
         if "x" in sv:
-            do2 = self._oproj_bwd(dx1, sv["x"], nm["xattn"], M, d)
+            do2 = self._oproj_bwd(dx1, sv["x"], nm["xattn"], M, d, sv["d_xo"])
             dnx = self.attn_bwd(do2, sv["x"], nm["xattn"], dkv_accum=denc)
             dx1 = self.ln_bwd(dnx, sv["lnx"], nm["lnx"][0], nm["lnx"][1] if not rms else None, M, d, rms=rms, dres=dx1)
-        do = self._oproj_bwd(dx1, sv["a"], nm["attn"], M, d)
+        do = self._oproj_bwd(dx1, sv["a"], nm["attn"], M, d, sv["d_o"])
         dn1 = self.attn_bwd(do, sv["a"], nm["attn"])
         return self.ln_bwd(dn1, sv["ln1"], nm["ln1"][0], nm["ln1"][1] if not rms else None, M, d, rms=rms, dres=dx1)
 
@@ -562,8 +587,9 @@ class Engine:
         else:
             fn = feat
         sv["fp_in"] = fn
+        sv["d_fp"] = self._dp(ec.feat_proj_dropout) if training else None      # TF:...wav2vec2.py:429-434
         h = self.lin(fn, self.W(ep + "feature_projection.projection.weight"), self.P(ep + "feature_projection.projection.bias"),
-                     M, d, C)
+                     M, d, C, drop=sv["d_fp"])
         sv["mask_rows"] = None
         if training and ec.apply_spec_augment and self.has(ep + "masked_spec_embed"):
             rows = self._spec_augment_rows(B, T)
@@ -572,10 +598,14 @@ class Engine:
                 sv["mask_rows"] = rows
         s, sv["pc"] = self.posconv_fwd(h, B, T)
         stable = ec.do_stable_layer_norm
+        d_in = self._dp(ec.hidden_dropout) if training else None                # TF:...wav2vec2.py:700-703 / 786-788
+        sv["d_in"] = d_in
         if not stable:
-            x, sv["enc_ln"] = self.ln_fwd(s, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps)
+            x, sv["enc_ln"] = self.ln_fwd(s, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps,
+                                          drop=d_in)
         else:
-            x = s
+            x = self._dropped(s, d_in, M * d)
+        drop = (ec.hidden_dropout, ec.attention_dropout, ec.activation_dropout) if training else None
         act = _act_id(ec.hidden_act)
         sv["layers"] = []
         hidden = [x]
@@ -585,7 +615,7 @@ class Engine:
                 hidden.append(x)
                 continue
             x, lsv = self.layer_fwd(x, B, T, d, ec.num_attention_heads, ec.intermediate_size, self._w2v2_layer_names(i),
-                                    stable, act, eps)
+                                    stable, act, eps, drop=drop)
             sv["layers"].append(lsv)
             hidden.append(x)
         if stable:
@@ -618,12 +648,15 @@ class Engine:
             self._stage(f"enc_layer{i}")
         if not stable:
             dx = self.ln_bwd(dx, sv["enc_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
+        else:
+            dx = self._dropped(dx, sv["d_in"], M * d)
         dh = self.posconv_bwd(dx, sv["pc"])
         if sv["mask_rows"] is not None:
             rows = sv["mask_rows"]
             me = ep + "masked_spec_embed"
             ops.mask_rows_bwd(dh, rows, rows.numel(), self.G(me) if self.tr(me) else None, d, self.dt)
         wn, bn = ep + "feature_projection.projection.weight", ep + "feature_projection.projection.bias"
+        dh = self._dropped(dh, sv["d_fp"], M * d)
         if self.tr(wn):
             self.wgrad(dh, sv["fp_in"], self.G(wn), M, d, C, gb=self.G(bn))
         dfn = self.new(M, C)
@@ -714,6 +747,10 @@ class Engine:
         escale = math.sqrt(d) if (lc.scale_embedding and not t5) else 1.0
         sv["emb_name"], sv["escale"] = emb_name, escale
         H, F = lc.encoder_attention_heads, lc.encoder_ffn_dim
+        # dropout sites: TF:models/bart/modeling_bart.py:826-829,1062-1064 (after layernorm_embedding) + the per-layer
+        # ones; T5: on the stack input and after the final norm (TF:models/t5/modeling_t5.py:1020,1101-1102)
+        drop = (lc.dropout, lc.attention_dropout, lc.activation_dropout) if training else None
+        pdrop = lc.dropout if training else 0.0
         # ---- text encoder
         if inputs_embeds is None:
             x = self.new(B * S, d)
@@ -728,21 +765,24 @@ class Engine:
                 raise NotImplementedError("gated T5 feed-forward is not on the SpeechMix path")
             ebias, _ = self._t5_bias("encoder", S, S)
             dbias, _ = self._t5_bias("decoder", Ld, Ld)
-            h = x
+            sv["d_enc_in"] = self._dp(pdrop)
+            h = self._dropped(x, sv["d_enc_in"], B * S * d)
             eps = lc.layer_norm_epsilon
         else:
             eps = 1e-5
             pe = lp + "model.encoder."
             h, sv["enc_emb_ln"] = self.ln_fwd(x, pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", B * S, d,
                                               eps, pos=self.W(pe + "embed_positions.weight"), pos_period=S, pos_offset=2,
-                                              want_sum=True)
+                                              want_sum=True, drop=self._dp(pdrop))
         sv["enc_layers"] = []
         for i in range(lc.encoder_layers):
             nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
-            h, lsv = self.layer_fwd(h, B, S, d, H, F, nm, pre_ln, act, eps, scale=1.0 if t5 else None, rms=t5, bias=ebias)
+            h, lsv = self.layer_fwd(h, B, S, d, H, F, nm, pre_ln, act, eps, scale=1.0 if t5 else None, rms=t5, bias=ebias,
+                                    drop=drop)
             sv["enc_layers"].append(lsv)
         if t5:
-            h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "encoder.final_layer_norm.weight", None, B * S, d, eps, rms=True)
+            h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "encoder.final_layer_norm.weight", None, B * S, d, eps, rms=True,
+                                                drop=self._dp(pdrop))
         elif lc.model_type == "mbart":
             h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "model.encoder.layer_norm.weight", lp + "model.encoder.layer_norm.bias",
                                                 B * S, d, eps)
@@ -757,15 +797,19 @@ class Engine:
             pd = lp + "model.decoder."
             y, sv["dec_emb_ln"] = self.ln_fwd(y, pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", B * Ld, d,
                                               eps, pos=self.W(pd + "embed_positions.weight"), pos_period=Ld, pos_offset=2,
-                                              want_sum=True)
+                                              want_sum=True, drop=self._dp(pdrop))
+        else:
+            sv["d_dec_in"] = self._dp(pdrop)
+            y = self._dropped(y, sv["d_dec_in"], B * Ld * d)
         sv["dec_layers"] = []
         for i in range(lc.decoder_layers):
             nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
             y, lsv = self.layer_fwd(y, B, Ld, d, Hd, Fd, nm, pre_ln, act, eps, causal=True, scale=1.0 if t5 else None,
-                                    enc=enc, Tk=S, rms=t5, bias=dbias)
+                                    enc=enc, Tk=S, rms=t5, bias=dbias, drop=drop)
             sv["dec_layers"].append(lsv)
         if t5:
-            y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "decoder.final_layer_norm.weight", None, B * Ld, d, eps, rms=True)
+            y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "decoder.final_layer_norm.weight", None, B * Ld, d, eps, rms=True,
+                                                drop=self._dp(pdrop))
         elif lc.model_type == "mbart":
             y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "model.decoder.layer_norm.weight", lp + "model.decoder.layer_norm.bias",
                                                 B * Ld, d, eps)
@@ -851,6 +895,8 @@ class Engine:
             pos_n = pd + "embed_positions.weight"
             dy = self.ln_bwd(dy, sv["dec_emb_ln"], pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", Md, d,
                              dpos=self.G(pos_n) if self.tr(pos_n) else None, pos_period=Ld, pos_offset=2)
+        if t5:
+            dy = self._dropped(dy, sv["d_dec_in"], Md * d)
         if self.tr(emb_name):
             ops.embed_bwd(sv["dec_ids"], dy, self.G(emb_name), Md, d, escale, self.dt)
         # ---- text encoder
@@ -870,6 +916,8 @@ class Engine:
             pos_n = pe + "embed_positions.weight"
             dh = self.ln_bwd(dh, sv["enc_emb_ln"], pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", Ms, d,
                              dpos=self.G(pos_n) if self.tr(pos_n) else None, pos_period=S, pos_offset=2)
+        if t5:
+            dh = self._dropped(dh, sv["d_enc_in"], Ms * d)
         if sv["enc_ids"] is not None:
             if self.tr(emb_name):
                 ops.embed_bwd(sv["enc_ids"], dh, self.G(emb_name), Ms, d, escale, self.dt)
@@ -878,6 +926,7 @@ class Engine:
 
     # ------------------------------------------------------------------ whole step
     def lm_losses(self, e, dec_ids, labels, B, S, Ld, text_ids=None, training=False, want_grad=True):
+        # `training` here is the LM's own mode (dropout): SpeechMixSelf keeps the LM in eval (ref:speechmix/model.py:239)
         """LM on `inputs_embeds` e [B*S,d] (+ optional SpeechMixSelf teacher pass on text_ids) -> losses and dlogits.
         Plain: CE (ref:speechmix/model.py:132-137).  Self: CE + KLD(batchmean) + MSE (ref:speechmix/model.py:235-266)."""
         logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training)
@@ -905,7 +954,8 @@ class Engine:
         out.update(loss=kld + ce + mse, ce=ce, kld=kld, mse=mse, dlogits=dlogits, extra_denc=dhs)
         return out
 
-    def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False):
+    def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False,
+                lm_training=None):
         """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf);
         prompt_ids [P] int64: token ids of a text prompt whose embeddings are prepended to every clip
         (ref:speechmix/model.py:168-171, batch-expanded like ref:speechmix/hf_model.py:433-436)."""
@@ -936,7 +986,8 @@ class Engine:
             # concatenation along time is pure data movement
             e = torch.cat((pe.view(1, P, dd).expand(B, P, dd), e.view(B, S, dd)), 1).contiguous().view(B * (P + S), dd)
             S = S + P
-        lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids, training=training)
+        lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
+                            training=training if lm_training is None else lm_training)
         self.saved = dict(speech=ssv, bridge=bsv, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], B=B, Ld=Ld,
                           ws=ws, P=P, prompt_ids=prompt_ids)
         return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=x, lm_enc_last=lo["lm_enc_last"],

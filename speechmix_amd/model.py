@@ -97,7 +97,7 @@ class _StepFn(torch.autograd.Function):
         text_ids, prompt_ids = model._pending_text_ids, model._pending_prompt_ids
         model._pending_text_ids = model._pending_prompt_ids = None
         out = model.engine.forward(wave, dec_ids, labels, training=training, text_ids=text_ids, prompt_ids=prompt_ids,
-                                   weighted_sum=model.weighted_sum)
+                                   weighted_sum=model.weighted_sum, lm_training=model._lm_training())
         ctx.model = model
         ctx.n_params = len(params)
         model._last = out
@@ -321,6 +321,13 @@ class SpeechMixEED(nn.Module):
         """ref:speechmix/model.py:132-137 - LM on `inputs_embeds` (no speech side, no autograd)."""
         return self._lm_only(inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids, labels=labels)
 
+    def _lm_training(self):
+        """Dropout mode of the LM: module state, like nn.Module.training drives HF's dropout calls; SpeechMixSelf
+        forces the LM to eval inside cal_loss (ref:speechmix/model.py:239)."""
+        if self._uses_text_ids:
+            self.decoder_model.eval()
+        return self.training and self.decoder_model.training
+
     # ------------------------------------------------------------------ forward (ref:speechmix/model.py:139-177)
     def forward(self, input_values, input_text_prompt=None, decoder_input_ids=None, labels=None,
                 return_model_detail=False, text_input_ids=None):
@@ -341,7 +348,7 @@ class SpeechMixEED(nn.Module):
                 prompt_ids = self.tokenizer(input_text_prompt, return_tensors="pt")["input_ids"].reshape(-1).to(self.device)
         dec = decoder_input_ids.to(self.device).contiguous()
         lab = labels.to(self.device).contiguous() if labels is not None else None
-        training = self.training and self.encoder_model.training
+        training = self.training and self.encoder_model.training     # dropout / LayerDrop / SpecAugment of the encoder
         return_dict = {}
         want_grad = torch.is_grad_enabled() and lab is not None and len(self.list_grad) > 0
         text = text_input_ids.to(self.device).contiguous() if (text_input_ids is not None and self._uses_text_ids) else None
@@ -351,8 +358,8 @@ class SpeechMixEED(nn.Module):
             loss = _StepFn.apply(self, wave, dec, lab, training, self._anchor, *params)
             out = self._last
         else:
-            out = self.engine.forward(wave, dec, lab, training=False, text_ids=text, prompt_ids=prompt_ids,
-                                      weighted_sum=self.weighted_sum)
+            out = self.engine.forward(wave, dec, lab, training=training, text_ids=text, prompt_ids=prompt_ids,
+                                      weighted_sum=self.weighted_sum, lm_training=self._lm_training())
             loss = out["loss"].view(()) if out["loss"] is not None else None
             self.engine.saved = None
         B, Ld = dec.shape

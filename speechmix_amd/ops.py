@@ -36,8 +36,9 @@ def view(ld, rows_per_batch=0, batch_stride=0, off=0):
 
 def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=None, bias=None, resid=None,
          aux_out=None, aux_in=None, act=ACT_NONE, out_f32=False, atomic=False, split_k=1, alpha=1.0, nbatch=1,
-         batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None, split_stride=0):
-    """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements."""
+         batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None, split_stride=0, drop=None):
+    """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements.
+    drop = (p, seed): dropout after the activation (before the residual add); mask index = m * N + n."""
     p = L.GemmParams()
     p.A, p.B, p.C = _ptr(a), _ptr(b), _ptr(c)
     p.bias, p.resid, p.aux_out, p.aux_in = _ptr(bias), _ptr(resid), _ptr(aux_out), _ptr(aux_in)
@@ -51,6 +52,8 @@ def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=N
     p.act, p.out_f32, p.atomic = act, int(out_f32), int(atomic)
     p.nbatch, p.split_k, p.tr_mode, p.alpha = nbatch, split_k, tr_mode, alpha
     p.split_stride = split_stride
+    if drop is not None and drop[0] > 0:
+        p.drop_p, p.drop_seed = drop
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = prof.events()
@@ -99,14 +102,16 @@ GEMM_PROFILE = None
 
 
 def norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dtype, eps=1e-5, rms=False, act=ACT_NONE, pos=None, pos_period=0,
-             pos_offset=0, xsum_out=None):
+             pos_offset=0, xsum_out=None, drop=None):
     p = L.NormParams(_ptr(x), _ptr(pos), _ptr(xsum_out), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                      M, D, pos_period, pos_offset, int(rms), act, eps)
+    if drop is not None and drop[0] > 0:
+        p.drop_p, p.drop_seed = drop
     L.check(L.lib().smx_norm_fwd(C.byref(p), dtype, _stream()), "smx_norm_fwd")
 
 
 def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms=False, act=ACT_NONE, dres=None,
-             dpos=None, pos_period=0, pos_offset=0):
+             dpos=None, pos_period=0, pos_offset=0, drop=None):
     ws = None
     if dgamma is not None or dbeta is not None:
         need = ((M + 15) // 16) * 2 * D
@@ -115,6 +120,8 @@ def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms
             ws = _NORM_WS[dy.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=dy.device)
     p = L.NormBwdParams(_ptr(dy), _ptr(x), _ptr(dres), _ptr(dx), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                         _ptr(dgamma), _ptr(dbeta), _ptr(dpos), _ptr(ws), M, D, pos_period, pos_offset, int(rms), act)
+    if drop is not None and drop[0] > 0:
+        p.drop_p, p.drop_seed = drop
     L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
 
 
@@ -124,10 +131,12 @@ _NORM_WS = {}
 class AttnDesc:
     """Strided description of Q/K/V/O living inside fused projection buffers (element units)."""
 
-    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None):
+    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None, drop=None):
         self.p = L.AttnParams()
         p = self.p
         p.B, p.H, p.Tq, p.Tk, p.D, p.causal, p.scale = B, H, Tq, Tk, D, int(causal), scale
+        if drop is not None and drop[0] > 0:
+            p.drop_p, p.drop_seed = drop
         p.bias = _ptr(bias)
         self._keep = [bias]
 
@@ -306,3 +315,8 @@ def weighted_sum_bwd(hidden, w, dy, dots, dw, sw, n, dtype):
 def axpy_dev(y, x, a, idx, n, init, dtype):
     L.check(L.lib().smx_axpy_dev(C.c_void_p(_ptr(y)), C.c_void_p(_ptr(x)), C.c_void_p(_ptr(a)), idx, C.c_longlong(n),
                                  int(init), dtype, _stream()), "smx_axpy_dev")
+
+
+def dropout(x, out, n, p, seed, dtype):
+    """out = x * mask(seed) / (1 - p), mask index = flat element index (same function the fused epilogues use)."""
+    L.check(L.lib().smx_dropout(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), C.c_longlong(n), C.c_float(p), C.c_uint(seed), dtype, _stream()), "smx_dropout")

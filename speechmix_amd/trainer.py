@@ -64,8 +64,9 @@ class StepRunner:
             decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
         self.reducer.begin_step()
         text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
-        out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(), training=m.training, text_ids=text,
-                          weighted_sum=m.weighted_sum)
+        out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(),
+                          training=m.training and m.encoder_model.training, text_ids=text, weighted_sum=m.weighted_sum,
+                          lm_training=m._lm_training())
         eng.backward(gscale=1.0, zero_grads=True)
         self.reducer.finish()
         self.t += 1
