@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout / LayerDrop / SpecAugment off")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -103,7 +104,9 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", share_layer_ratio=0, down_scale=2,
                              compute_dtype="bf16", init_seed=0)
-    model.eval()          # deterministic step: dropout / layerdrop / SpecAugment off (reported as dropout p=0)
+    # Training mode like HF Trainer's model.train(): dropout (hidden/attention/activation p=0.1 in the encoder, p=0.1
+    # in BART), LayerDrop and SpecAugment are ON with the HF config defaults; --eval-mode switches them off.
+    model.train(not args.eval_mode)
     runner = StepRunner(model, lr=4e-5, optimizer="adamw", max_grad_norm=1.0)
     B = args.batch
     wave, labels = synth_batch(B, model.decoder_model.config.vocab_size, rank, device)
@@ -133,13 +136,17 @@ def main():
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
+        ec, lc = model.encoder_model.config, model.decoder_model.config
+        mode = ("eval mode (dropout/LayerDrop/SpecAugment off)" if args.eval_mode else
+                f"train mode: encoder dropout {ec.hidden_dropout}/{ec.attention_dropout}/{ec.activation_dropout}, "
+                f"LayerDrop {ec.layerdrop}, SpecAugment p={ec.mask_time_prob}, LM dropout {lc.dropout}")
         value = world * B * CLIP_SECONDS * args.steps / elapsed
         line = {"metric": "audio-seconds/sec per training step, wav2vec2-base->bart-base", "value": round(value, 1),
                 "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "SpeechMixEED wav2vec2-base + bart-base, 32 x 10 s clips/GPU, down_scale=2, "
-                                       "32 label tokens, fwd+bwd+allreduce+clip+AdamW, dropout p=0",
+                                       "32 label tokens, fwd+bwd+allreduce+clip+AdamW, " + mode,
                            "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
                 "final_loss": round(final_loss, 4)}
         if prof is not None:

@@ -13,6 +13,7 @@ fp32 straight into the FlatStore's flat gradient buffer (the thing RCCL all-redu
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -45,8 +46,9 @@ class Engine:
         self.ep, self.lp = enc_prefix, lm_prefix
         self._persist: Dict[str, torch.Tensor] = {}
         self.saved = None
-        self.rng = np.random.default_rng(0)
-        self.drop_rng = np.random.default_rng(0x5eed)   # per-site dropout seeds (masks are regenerated in backward)
+        rank = int(os.environ.get("RANK", "0"))         # independent draws per data-parallel rank
+        self.rng = np.random.default_rng(rank)
+        self.drop_rng = np.random.default_rng(0x5eed + rank)   # per-site dropout seeds (masks are regenerated in backward)
         self.stage_cb = None      # callable(stage_name): gradient ranges of that stage are final (dist.GradReducer)
 
     def _dp(self, p):

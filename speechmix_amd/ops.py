@@ -68,8 +68,8 @@ def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=N
 class GemmProfile:
     """Live per-launch timing of the GEMM kernel variants with HIP events on the launch stream (bench.py).
     Variants: (a_rc, b_rc) = (0,0) forward, (0,1) data gradient, (1,1) weight gradient."""
-    NAMES = {(0, 0): "gemm_bf16_kernel<KC,KC> (fwd)", (0, 1): "gemm_bf16_kernel<KC,RC> (dgrad)",
-             (1, 1): "gemm_bf16_kernel<RC,RC> (wgrad)", (1, 0): "gemm_bf16_kernel<RC,KC>"}
+    NAMES = {(0, 0): "gemm_bf16_dma_kernel<false,false> (fwd)", (0, 1): "gemm_bf16_dma_kernel<false,true> (dgrad)",
+             (1, 1): "gemm_bf16_dma_kernel<true,true> (wgrad)", (1, 0): "gemm_bf16_dma_kernel<true,false>"}
 
     def __init__(self):
         self.pool, self.used, self.recs = [], 0, []
