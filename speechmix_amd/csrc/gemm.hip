@@ -358,6 +358,121 @@ struct DmaLoader {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Row-major epilogue for the MFMA kernels.  The accumulator layout (lane = one m, 4 consecutive n per 16x16 block)
+// gives 8-byte accesses scattered over 16 rows and one address computation per block; measured on the FFN shapes
+// that epilogue cost as much as the whole K loop.  Here each wave transposes its 64x64 fp32 sub-tile through a
+// wave-private 8-KB LDS slice (two halves of 32 rows, XOR-swizzled 16-B chunks: conflict-free both ways), after
+// which a lane owns 8 consecutive n of one row: one address per row visit, 16-B loads of resid / aux_in, 16-B
+// stores of C / aux_out (128 contiguous bytes per 8 lanes), bias held in registers for the whole tile.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long zc, long long ze, int m, int n, float x[8],
+                                              const float bs[8], unsigned th, float inv_keep) {
+    const long long base = zc + view_off(p.c, m) + n;
+    const bool side = p.resid || p.aux_out || p.aux_in;
+    const long long sb = side ? ze + view_off(p.e, m) + n : 0;
+    const int nv = min(8, p.N - n);
+    const bool fast = nv == 8 && !(base & 7) && !(sb & 7);
+    const bf16_t* aux_in = reinterpret_cast<const bf16_t*>(p.aux_in);
+    const bf16_t* resid = reinterpret_cast<const bf16_t*>(p.resid);
+    bf16_t* aux_out = reinterpret_cast<bf16_t*>(p.aux_out);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[e]);
+    if (fast) {
+        if (aux_out) store8(aux_out + sb, x);
+        if (aux_in) {
+            float a[8];
+            load8(aux_in + sb, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= act_grad(a[e], p.act);
+        } else if (p.act) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = act_fwd(x[e], p.act);
+        }
+        if (p.drop_p > 0.f) {
+            const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
+        }
+        if (resid) {
+            float r[8];
+            load8(resid + sb, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += r[e];
+        }
+        if (!p.out_f32) {
+            store8(reinterpret_cast<bf16_t*>(p.C) + base, x);
+        } else {
+            float* c = reinterpret_cast<float*>(p.C) + base;
+            if (p.atomic == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(c + e, x[e]);
+            } else {
+                if (p.atomic == 2) {
+                    float o[8];
+                    load8(c, o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += o[e];
+                }
+                store8(c, x);
+            }
+        }
+        return;
+    }
+    // ragged / unaligned tail (LM head with V % 8 != 0, odd views): element-wise
+    for (int e = 0; e < nv; ++e) {
+        float v = x[e];
+        if (aux_out) aux_out[sb + e] = f2bf(v);
+        if (aux_in) v *= act_grad(bf2f(aux_in[sb + e]), p.act);
+        else v = act_fwd(v, p.act);
+        if (p.drop_p > 0.f) v *= smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n + e + zc), th, inv_keep);
+        if (resid) v += bf2f(resid[sb + e]);
+        if (!p.out_f32) {
+            reinterpret_cast<bf16_t*>(p.C)[base + e] = f2bf(v);
+        } else {
+            float* c = reinterpret_cast<float*>(p.C) + base + e;
+            if (p.atomic == 1) atomicAdd(c, v);
+            else if (p.atomic == 2) *c += v;
+            else *c = v;
+        }
+    }
+}
+
+// acc[i][j]: 16x16 block (rows mw0 + 16 i .., cols nw0 + 16 j ..) of this wave's 64x64 sub-tile; wbuf: 8 KB of LDS
+// owned by this wave (no other wave touches it between the caller's barriers).
+__device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
+                                                long long zc, long long zbias, long long ze, int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+    const int rr = lane >> 3, cc = lane & 7;
+    const int n = nw0 + cc * 8;
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = (p.bias && n + e < p.N) ? p.bias[zbias + n + e] : 0.f;
+    const unsigned th = smx_thresh24(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lr = i2 * 16 + i16, c = j * 4 + g;
+                *reinterpret_cast<f32x4_t*>(wbuf + lr * 256 + ((c ^ (lr & 15)) << 4)) = acc[2 * h + i2][j];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lr = q * 8 + rr;
+            const int m = mw0 + h * 32 + lr;
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc) ^ (lr & 15)) << 4));
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc + 1) ^ (lr & 15)) << 4));
+            if (m < p.M && n < p.N) {
+                float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                epilogue_row8(p, zc, ze, m, n, x, bs, th, inv_keep);
+            }
+        }
+    }
+}
+
 template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -428,14 +543,9 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) 
         }
         __syncthreads();                 // everyone is done reading before the next fill overwrites the tile
     }
-    const int g = lane >> 4, i16 = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epilogue4<bf16_t>(p, zc, zbias, ze, m0 + wm * 64 + i * 16 + i16, n0 + wn * 64 + j * 16 + 4 * g, v);
-        }
+    // the K loop ended on a barrier: the tile buffers are free, each wave transposes through its own 8-KB slice
+    epilogue_staged(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, zc, zbias, ze, lane);
+    if (lin + (int)gridDim.x < nwg) __syncthreads();   // slices are tile memory again for the next fill
     }   // tile loop
 }
 

@@ -25,15 +25,15 @@ enum { SMX_F32 = 0, SMX_BF16 = 1 };
 
 // ---- bf16 <-> f32 ----
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                           // round-nearest-even
-    return (bf16_t)(u >> 16);
-}
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN): one instruction per pair
+typedef __attribute__((ext_vector_type(2))) float smx_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 smx_bf16x2_t;
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    union { smx_bf16x2_t b; unsigned u; } c;
+    c.b = __builtin_convertvector((smx_f32x2_t){lo, hi}, smx_bf16x2_t);
+    return c.u;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {

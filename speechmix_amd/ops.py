@@ -60,7 +60,7 @@ def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=N
         e0.record()
         L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
         e1.record()
-        prof.add((int(a_rc), int(b_rc)), e0, e1, 2.0 * M * N * K * nbatch)
+        prof.add((int(a_rc), int(b_rc)), e0, e1, 2.0 * M * N * K * nbatch, (M, N, K, nbatch, split_k))
         return
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
 
@@ -81,13 +81,23 @@ class GemmProfile:
         self.used += 2
         return e
 
-    def add(self, key, e0, e1, flops):
-        self.recs.append((key, e0, e1, flops))
+    def add(self, key, e0, e1, flops, shape=None):
+        self.recs.append((key, e0, e1, flops, shape))
+
+    def by_shape(self):
+        """-> {(variant, (M, N, K, nbatch, split_k)): dict(launches, total_ms, flops)} (tools/gpu_gemm_shapes.py)."""
+        out = {}
+        for key, e0, e1, fl, shape in self.recs:
+            d = out.setdefault((key, shape), dict(launches=0, total_ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+        return out
 
     def summary(self):
         """-> {variant: dict(launches, total_ms, avg_us, flops, tflops)}; call after a device synchronize."""
         out = {}
-        for key, e0, e1, fl in self.recs:
+        for key, e0, e1, fl, _ in self.recs:
             d = out.setdefault(key, dict(launches=0, total_ms=0.0, flops=0.0))
             d["launches"] += 1
             d["total_ms"] += e0.elapsed_time(e1)

@@ -1,0 +1,31 @@
+"""Per-shape GEMM timing inside the real training step (HIP events around every smx_gemm launch)."""
+import contextlib, io, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from speechmix_amd import ops
+from speechmix_amd.model import SpeechMixEED
+from speechmix_amd.trainer import StepRunner
+from bench import synth_batch
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+with contextlib.redirect_stdout(io.StringIO()):
+    model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", share_layer_ratio=0, down_scale=2, compute_dtype="bf16")
+model.eval()
+runner = StepRunner(model)
+wave, labels = synth_batch(32, model.decoder_model.config.vocab_size, 0, torch.device("cuda:0"))
+for _ in range(2):
+    runner.step(wave, labels)
+prof = ops.GemmProfile()
+ops.GEMM_PROFILE = prof
+for _ in range(steps):
+    runner.step(wave, labels)
+torch.cuda.synchronize()
+ops.GEMM_PROFILE = None
+rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["total_ms"])
+tot = sum(d["total_ms"] for _, d in rows) / steps
+print(f"GEMM total {tot:.2f} ms/step")
+names = {(0, 0): "fwd  ", (0, 1): "dgrad", (1, 1): "wgrad", (1, 0): "rc_kc"}
+for (var, shape), d in rows[:60]:
+    M, N, K, nb, sk = shape
+    print(f"{d['total_ms']/steps:7.3f} ms/step {d['launches']/steps:5.1f}x avg {1e3*d['total_ms']/d['launches']:8.1f} us "
+          f"{d['flops']/d['total_ms']/1e9:7.1f} TF/s  {names[var]} M={M:7d} N={N:6d} K={K:7d} nb={nb} split={sk}")
