@@ -40,6 +40,8 @@ typedef struct SmxGemmParams {
     float drop_p; unsigned drop_seed;   /* dropout after the activation, before the residual (see "dropout" below) */
 } SmxGemmParams;
 int smx_gemm(const SmxGemmParams* p, int dtype, hipStream_t stream);
+/* second stage of a split-K forward / data-gradient GEMM: C = epilogue(sum_s slabs[s]); slabs: nsplit x [M, ldn] fp32 */
+int smx_gemm_splitk_epilogue(const SmxGemmParams* p, const float* slabs, int nsplit, long long stride, int ldn, hipStream_t stream);
 int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stride, float* dst, int accumulate, hipStream_t stream);
 
 /* LayerNorm / RMSNorm (+ fused positional-table add, + fused activation) forward and backward.

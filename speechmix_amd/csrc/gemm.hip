@@ -313,6 +313,16 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_vp_t)src, (lds_vp_t)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ void glds16_asm(const bf16_t* src, const char* lds_wave_base) {
+    typedef __attribute__((address_space(3))) const char* lds_cp_t;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+}
+
 template <bool RC>
 struct DmaLoader {
     // Minimal per-thread state (this kernel lives on a 128-register budget): KC keeps one 32-bit element offset per
@@ -337,13 +347,19 @@ struct DmaLoader {
             }
         }
     }
+    // ASM: issue through inline asm so that hipcc does not drain the DMA queue (s_waitcnt vmcnt(0)) before the next
+    // LDS read - the pipelined kernels count their own waits
+    template <bool ASM = false>
     __device__ __forceinline__ void issue(char* tile, const SmxRowView& v, int row0, int nrows, int k0, int K, int tid) {
         const int lane = tid & 63, wave = tid >> 6;
         if (!RC) {
             const bool kin = k0 + kc < K;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                glds16((kin && off[p] >= 0) ? base + off[p] + k0 : zero, tile + (p * 32 + wave * 8) * 128);
+            for (int p = 0; p < 4; ++p) {
+                const bf16_t* src = (kin && off[p] >= 0) ? base + off[p] + k0 : zero;
+                if (ASM) glds16_asm(src, tile + (p * 32 + wave * 8) * 128);
+                else glds16(src, tile + (p * 32 + wave * 8) * 128);
+            }
         } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -352,7 +368,8 @@ struct DmaLoader {
                 const int c = row0 + ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
                 const bf16_t* src = zero;
                 if (k0 + kl < K && c < nrows) src = base + view_off(v, k0 + kl) + c;
-                glds16(src, tile + (p * 16 + wave * 4) * 256);
+                if (ASM) glds16_asm(src, tile + (p * 16 + wave * 4) * 256);
+                else glds16(src, tile + (p * 16 + wave * 4) * 256);
             }
         }
     }
@@ -558,15 +575,6 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) 
 // The barrier publishes stage ks and guarantees every wave is done reading stage ks-1 - the slot being refilled.
 // The DMA is issued from inline asm so that hipcc neither drains it before the ds_reads nor before the barrier.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16_asm(const bf16_t* src, const char* lds_wave_base) {
-    typedef __attribute__((address_space(3))) const char* lds_cp_t;
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp_t)lds_wave_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(dst)
-                 : "memory");
-}
 
 template <bool RC, int ROWS, int NW>   // ROWS: tile rows (KC) / columns (RC) of this operand; NW waves in the workgroup
 struct BigLoader {
@@ -1066,6 +1074,43 @@ extern "C" int smx_reduce_slabs(const float* slabs, int nsplit, long long n, lon
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, slabs, nsplit, n, stride, dst, accumulate);
+    SMX_CHECK_LAUNCH();
+}
+
+// Second stage of a split-K forward / data-gradient GEMM (outputs with fewer tiles than CUs: the decoder, the LM head):
+// C = epilogue(sum_s slabs[s]) with the full epilogue of SmxGemmParams (bias, activation or activation gradient,
+// dropout, residual, aux_out, bf16 / fp32 / accumulate).  slabs: nsplit x [M, ldn] fp32, rows padded to ldn % 8 == 0.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(SmxGemmParams p, const float* __restrict__ slabs, int nsplit,
+                                                              long long stride, int ldn) {
+    const int chunks = (p.N + 7) >> 3;
+    const long long total = (long long)p.M * chunks;
+    const unsigned th = smx_thresh24(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks), n = (int)(i - (long long)m * chunks) * 8;
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* src = slabs + (long long)m * ldn + n;
+        for (int s = 0; s < nsplit; ++s) {
+            float v[8];
+            load8(src + s * stride, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += v[e];
+        }
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
+        epilogue_row8(p, 0, 0, m, n, x, bs, th, inv_keep);
+    }
+}
+extern "C" int smx_gemm_splitk_epilogue(const SmxGemmParams* pp, const float* slabs, int nsplit, long long stride, int ldn,
+                                        hipStream_t stream) {
+    (void)hipGetLastError();
+    SmxGemmParams p = *pp;
+    if (p.M <= 0 || p.N <= 0 || nsplit < 1 || (ldn & 7) || ldn < p.N || (stride & 7) || p.nbatch > 1) return SMX_EINVAL;
+    const long long total = (long long)p.M * ((p.N + 7) >> 3);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, p, slabs, nsplit, stride, ldn);
     SMX_CHECK_LAUNCH();
 }
 

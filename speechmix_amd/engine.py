@@ -106,19 +106,43 @@ class Engine:
         return (ksteps + per - 1) // per
 
     # ------------------------------------------------------------------ linear building blocks
+    def _fsplit(self, Mo, No, Kred, kw):
+        """Split factor for a forward / data-gradient GEMM whose output has fewer tiles than the chip has CUs (decoder
+        side, LM-head gradient): a lone workgroup per CU is bound by that CU's fetch rate, so spread K over idle CUs."""
+        if self.dt != BF16 or kw.get("nbatch", 1) > 1 or kw.get("atomic") or kw.get("split_k", 1) > 1:
+            return 1
+        tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
+        ksteps = (Kred + 63) // 64
+        if tiles > 256 or ksteps < 6:
+            return 1
+        # up to 4 resident workgroups per CU; keep >= 3-4 K steps per split (slab traffic grows with the split count)
+        want = int(min(1024 // tiles, ksteps // 3 if ksteps <= 16 else ksteps // 4, 24))
+        if want < 2:
+            return 1
+        per = (ksteps + want - 1) // want
+        return (ksteps + per - 1) // per
+
+    def _gemm(self, a, b, c, M, N, K, **kw):
+        split = self._fsplit(M, N, K, kw)
+        if split > 1 and kw.get("cv") is None:
+            slabs = self.workspace("fwd_slabs", split * M * ((N + 7) // 8 * 8), torch.float32)
+            ops.gemm_splitk(a, b, c, M, N, K, self.dt, split, slabs, **kw)
+        else:
+            ops.gemm(a, b, c, M, N, K, self.dt, **kw)
+
     def lin(self, x, w, b, M, N, K, y=None, act=ACT_NONE, resid=None, aux_out=None, av=None, cv=None, ev=None,
             alpha=1.0, out_f32=False, **kw):
         if y is None:
             y = self.new(M, N, dt=torch.float32 if out_f32 else None)
-        ops.gemm(x, w, y, M, N, K, self.dt, av=av, cv=cv, ev=ev, bias=b, resid=resid, aux_out=aux_out, act=act,
-                 alpha=alpha, out_f32=out_f32, **kw)
+        self._gemm(x, w, y, M, N, K, av=av, cv=cv, ev=ev, bias=b, resid=resid, aux_out=aux_out, act=act,
+                   alpha=alpha, out_f32=out_f32, **kw)
         return y
 
     def dgrad(self, dy, w, dx, M, N, K, resid=None, aux_in=None, act=ACT_NONE, av=None, bv=None, cv=None, ev=None,
               alpha=1.0, **kw):
         """dx[M,K] = dy[M,N] @ w[N,K]   (w read rows-contiguous: no transposed weight copy)."""
-        ops.gemm(dy, w, dx, M, K, N, self.dt, b_rc=True, av=av, bv=bv if bv is not None else view(K), cv=cv, ev=ev,
-                 resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
+        self._gemm(dy, w, dx, M, K, N, b_rc=True, av=av, bv=bv if bv is not None else view(K), cv=cv, ev=ev,
+                   resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
         return dx
 
     def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, **kw):

@@ -34,11 +34,9 @@ def view(ld, rows_per_batch=0, batch_stride=0, off=0):
     return L.RowView(batch_stride, ld, off, rows_per_batch, 0)
 
 
-def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=None, bias=None, resid=None,
-         aux_out=None, aux_in=None, act=ACT_NONE, out_f32=False, atomic=False, split_k=1, alpha=1.0, nbatch=1,
-         batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None, split_stride=0, drop=None):
-    """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements.
-    drop = (p, seed): dropout after the activation (before the residual add); mask index = m * N + n."""
+def _gemm_params(a, b, c, M, N, K, a_rc=False, b_rc=False, av=None, bv=None, cv=None, bias=None, resid=None,
+                 aux_out=None, aux_in=None, act=ACT_NONE, out_f32=False, atomic=False, split_k=1, alpha=1.0, nbatch=1,
+                 batch_a=0, batch_b=0, batch_c=0, batch_bias=0, tr_mode=1, ev=None, batch_e=None, split_stride=0, drop=None):
     p = L.GemmParams()
     p.A, p.B, p.C = _ptr(a), _ptr(b), _ptr(c)
     p.bias, p.resid, p.aux_out, p.aux_in = _ptr(bias), _ptr(resid), _ptr(aux_out), _ptr(aux_in)
@@ -54,15 +52,35 @@ def gemm(a, b, c, M, N, K, dtype, a_rc=False, b_rc=False, av=None, bv=None, cv=N
     p.split_stride = split_stride
     if drop is not None and drop[0] > 0:
         p.drop_p, p.drop_seed = drop
+    return p
+
+
+def gemm(a, b, c, M, N, K, dtype, **kw):
+    """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements.
+    drop = (p, seed): dropout after the activation (before the residual add); mask index = m * N + n."""
+    p = _gemm_params(a, b, c, M, N, K, **kw)
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = prof.events()
         e0.record()
         L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
         e1.record()
-        prof.add((int(a_rc), int(b_rc)), e0, e1, 2.0 * M * N * K * nbatch, (M, N, K, nbatch, split_k))
+        prof.add((p.a_rc, p.b_rc), e0, e1, 2.0 * M * N * K * p.nbatch, (M, N, K, p.nbatch, p.split_k))
         return
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+
+
+def gemm_splitk(a, b, c, M, N, K, dtype, split, slabs, **kw):
+    """Split-K form of `gemm` for outputs with too few tiles to fill the chip: `split` K-slices write fp32 partial slabs
+    (slabs: >= split * M * ceil8(N) floats), one streaming pass sums them and applies the whole epilogue."""
+    ldn = (N + 7) // 8 * 8
+    stride = M * ldn
+    plain = {k: kw[k] for k in ("a_rc", "b_rc", "av", "bv", "tr_mode") if k in kw}
+    gemm(a, b, slabs, M, N, K, dtype, cv=view(ldn), out_f32=True, split_k=split, split_stride=stride, **plain)
+    epi = {k: v for k, v in kw.items() if k not in ("av", "bv", "tr_mode")}
+    p = _gemm_params(a, b, c, M, N, K, **epi)
+    L.check(L.lib().smx_gemm_splitk_epilogue(C.byref(p), C.c_void_p(_ptr(slabs)), split, C.c_longlong(stride), ldn, _stream()),
+            "smx_gemm_splitk_epilogue")
 
 
 class GemmProfile:

@@ -92,26 +92,46 @@ static float time_us(F&& f, int n = 20) {
 }
 
 int main(int argc, char** argv) {
-    const int shapes[][3] = {{15968, 3072, 768}, {15968, 768, 3072}, {15968, 768, 768}, {16384, 4096, 1024}, {1024, 768, 768}};
+    const bool stripped = argc > 1 && atoi(argv[1]) == 1;
+    const int shapes[][3] = {{15968, 3072, 768}, {15968, 768, 3072}, {15968, 768, 768}, {16384, 4096, 1024}, {1024, 768, 768},
+                             {1024, 768, 3072}, {1024, 3072, 768}, {7968, 768, 768}};
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
         bf16_t *A, *B, *C;
         CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
         CK(hipMemset(A, 0x3c, (size_t)M * K * 2)); CK(hipMemset(B, 0x3c, (size_t)N * K * 2));
-        SmxGemmParams p = {};
-        p.A = A; p.B = B; p.C = C;
-        p.a = SmxRowView{0, K, 0, 0, 0}; p.b = SmxRowView{0, K, 0, 0, 0}; p.c = SmxRowView{0, N, 0, 0, 0}; p.e = p.c;
-        p.M = M; p.N = N; p.K = K; p.nbatch = 1; p.split_k = 1; p.tr_mode = 1; p.alpha = 1.f;
         const double fl = 2.0 * M * N * K;
         int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        dim3 grid(tiles > 1024 ? 1024 : tiles);
-        float t_full = time_us([&] { smx_gemm(&p, SMX_BF16, 0); });
-        float t0 = time_us([&] { hipLaunchKernelGGL(lab_kernel<0>, grid, dim3(256), 32768, 0, p); });
-        float t1 = time_us([&] { hipLaunchKernelGGL(lab_kernel<1>, grid, dim3(256), 32768, 0, p); });
-        float t2 = time_us([&] { hipLaunchKernelGGL(lab_kernel<2>, grid, dim3(256), 32768, 0, p); });
-        const double bytes = (double)tiles * ((K + 63) / 64) * 32768.0;
-        printf("M=%d N=%d K=%d tiles=%d: production %.1f us (%.0f TF) | no-epilogue %.1f us (%.0f TF) | loads-only %.1f us (%.2f TB/s L2->LDS) | "
-               "compute-only %.1f us (%.0f TF)\n", M, N, K, tiles, t_full, fl / t_full / 1e6, t0, fl / t0 / 1e6, t1, bytes / t1 / 1e6, t2, fl / t2 / 1e6);
+        SmxGemmParams p = {};
+        p.A = A; p.B = B; p.C = C;
+        p.c = SmxRowView{0, N, 0, 0, 0}; p.e = p.c;
+        p.M = M; p.N = N; p.K = K; p.nbatch = 1; p.split_k = 1; p.alpha = 1.f;
+        if (stripped) {
+            p.a = SmxRowView{0, K, 0, 0, 0}; p.b = SmxRowView{0, K, 0, 0, 0}; p.tr_mode = 1;
+            dim3 grid(tiles > 1024 ? 1024 : tiles);
+            float t_full = time_us([&] { smx_gemm(&p, SMX_BF16, 0); });
+            float t0 = time_us([&] { hipLaunchKernelGGL(lab_kernel<0>, grid, dim3(256), 32768, 0, p); });
+            float t1 = time_us([&] { hipLaunchKernelGGL(lab_kernel<1>, grid, dim3(256), 32768, 0, p); });
+            float t2 = time_us([&] { hipLaunchKernelGGL(lab_kernel<2>, grid, dim3(256), 32768, 0, p); });
+            const double bytes = (double)tiles * ((K + 63) / 64) * 32768.0;
+            printf("M=%d N=%d K=%d tiles=%d: production %.1f us (%.0f TF) | no-epilogue %.1f us (%.0f TF) | loads-only %.1f us (%.2f TB/s L2->LDS) | "
+                   "compute-only %.1f us (%.0f TF)\n", M, N, K, tiles, t_full, fl / t_full / 1e6, t0, fl / t0 / 1e6, t1, bytes / t1 / 1e6, t2, fl / t2 / 1e6);
+        } else {
+            printf("M=%d N=%d K=%d tiles=%d:", M, N, K, tiles);
+            const int rcs[3][2] = {{0, 0}, {0, 1}, {1, 1}};
+            for (auto& rc : rcs) {
+                p.a_rc = rc[0]; p.b_rc = rc[1];
+                p.a = SmxRowView{0, rc[0] ? M : K, 0, 0, 0};
+                p.b = SmxRowView{0, rc[1] ? N : K, 0, 0, 0};
+                printf("  [a_rc=%d b_rc=%d]", rc[0], rc[1]);
+                for (int tr : {1}) {
+                    p.tr_mode = tr;
+                    float t = time_us([&] { if (smx_gemm(&p, SMX_BF16, 0)) { printf("launch failed\n"); exit(1); } });
+                    printf(" tr%d %.1fus(%.0fTF)", tr, t, fl / t / 1e6);
+                }
+            }
+            printf("\n");
+        }
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
     }
     return 0;
