@@ -203,252 +203,431 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 #define ZERO4 ((f32x4_t){0.f, 0.f, 0.f, 0.f})
 
-__global__ __launch_bounds__(256) void attn_fwd_bf16(SmxAttnParams p) {
-    __shared__ __attribute__((aligned(16))) char sK[8192];
-    __shared__ __attribute__((aligned(16))) char sV[8192];
+#define SMX_LOG2E 1.44269504088896340736f
+#define SMX_LN2 0.69314718055994530942f
+// raw v_exp_f32 (2^x): the softmax runs in the log2 domain so that scale, shift and exponent are one v_fma + one v_exp
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// global -> registers -> LDS staging of a [64][64] bf16 tile, split so that the global loads of the NEXT tile are in
+// flight while the current one is consumed (one barrier per tile, two LDS buffers)
+__device__ __forceinline__ void tile_load(uint4 (&v)[2], const bf16_t* base, long long ld, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        const int r = (tid >> 3) + 32 * pss, c = tid & 7;
+        v[pss] = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nrows) v[pss] = *reinterpret_cast<const uint4*>(base + (long long)(row0 + r) * ld + c * 8);
+    }
+}
+__device__ __forceinline__ void tile_store(char* tile, const uint4 (&v)[2], int tid) {
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) *reinterpret_cast<uint4*>(tile + t_addr((tid >> 3) + 32 * pss, (tid & 7) * 8)) = v[pss];
+}
+__device__ __forceinline__ bf16x8_t load_row_frag(const bf16_t* base, long long ld, int row, int nrows, int kk, int g) {
+    union { bf16x8_t v; uint4 u; } f;
+    f.u = make_uint4(0, 0, 0, 0);
+    if (row < nrows) f.u = *reinterpret_cast<const uint4*>(base + (long long)row * ld + kk * 32 + g * 8);
+    return f.v;
+}
+
+// Forward: block = 64 U queries (wave: U 16-query column blocks), loops over 64-key tiles.  S^T = K Q^T so that the
+// probabilities of a 16x16 block are directly the B operand of the P V product ("pair" k-slot mapping, see frag_tr).
+template <int U>
+__global__ __launch_bounds__(256, U == 1 ? 4 : 2) void attn_fwd_bf16(SmxAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sK[2][8192];
+    __shared__ __attribute__((aligned(16))) char sV[2][8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
-    const int q = q0 + i16;                       // this lane's query column
+    const int b = blockIdx.z, h = blockIdx.y, qw0 = blockIdx.x * (64 * U) + wave * (16 * U);
     const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * 64;
     const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * 64;
     const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * 64;
-    bf16x8_t qf[2];
+    bf16x8_t qf[U][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        union { bf16x8_t v; uint4 u; } f;
-        f.u = make_uint4(0, 0, 0, 0);
-        if (q < p.Tq) f.u = *reinterpret_cast<const uint4*>(Qp + (long long)q * p.q_ld + kk * 32 + g * 8);
-        qf[kk] = f.v;
-    }
-    f32x4_t o[4] = {ZERO4, ZERO4, ZERO4, ZERO4};
-    float m = NEG_BIG, l = 0.f;
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[u][kk] = load_row_frag(Qp, p.q_ld, qw0 + u * 16 + i16, p.Tq, kk, g);
+    f32x4_t o[U][4];
+    float m[U], l[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[u][dt] = ZERO4;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { m[u] = NEG_BIG; l[u] = 0.f; }
+    const float sl2 = p.scale * SMX_LOG2E;
     const int coff = p.Tk - p.Tq;
     int kend = p.Tk;
-    if (p.causal) kend = min(p.Tk, blockIdx.x * 64 + 64 + coff);   // keys beyond the block's last query are masked
+    if (p.causal) kend = min(p.Tk, (int)blockIdx.x * (64 * U) + 64 * U + coff);   // keys beyond the block's last query are masked
+    uint4 rk[2], rv[2];
+    tile_load(rk, Kp, p.k_ld, 0, p.Tk, tid);
+    tile_load(rv, Vp, p.v_ld, 0, p.Tk, tid);
+    tile_store(sK[0], rk, tid);
+    tile_store(sV[0], rv, tid);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = 0; k0 < kend; k0 += 64) {
-        __syncthreads();
-        stage_tile(sK, Kp, p.k_ld, k0, p.Tk, tid);
-        stage_tile(sV, Vp, p.v_ld, k0, p.Tk, tid);
-        __syncthreads();
-        f32x4_t s[4];
+        const bool more = k0 + 64 < kend;
+        if (more) {
+            tile_load(rk, Kp, p.k_ld, k0 + 64, p.Tk, tid);
+            tile_load(rv, Vp, p.v_ld, k0 + 64, p.Tk, tid);
+        }
+        const char* tK = sK[buf];
+        const char* tV = sV[buf];
+        f32x4_t s[U][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            s[t] = ZERO4;
+            const bf16x8_t k0f = frag_kc(tK, t * 16, 0, lane), k1f = frag_kc(tK, t * 16, 1, lane);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sK, t * 16, kk, lane), qf[kk], s[t], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                s[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[u][0], ZERO4, 0, 0, 0);
+                s[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[u][1], s[u][t], 0, 0, 0);
+            }
         }
-        float mx = NEG_BIG;
+        // masks only where they can bite: the ragged last key tile, and tiles crossing the causal diagonal
+        const bool masked = (k0 + 64 > p.Tk) || (p.causal && k0 + 63 > (int)blockIdx.x * (64 * U) + coff);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int u = 0; u < U; ++u) {
+            const int q = qw0 + u * 16 + i16;
+            float mul = sl2;
+            if (p.bias) {                                  // T5 relative-position bias: scores leave this block in log2 units
+                mul = 1.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + t * 16 + 4 * g + r;
-                float v = s[t][r] * p.scale;
-                if (p.bias && q < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + q) * p.Tk + key];
-                if (key >= p.Tk || (p.causal && key > q + coff)) v = -INFINITY;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + t * 16 + 4 * g + r;
+                        float v = s[u][t][r] * sl2;
+                        if (q < p.Tq && key < p.Tk) v = fmaf(p.bias[((long long)h * p.Tq + q) * p.Tk + key], SMX_LOG2E, v);
+                        s[u][t][r] = v;
+                    }
             }
-        mx = group_max(mx);
-        const float mn = fmaxf(m, mx);
-        const float alpha = __expf(m - mn);
-        float rs = 0.f;
+            if (masked) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[t][r] - mn);
-                rs += e;
-                s[t][r] = p.drop_p > 0.f ? e * ATT_DROP(p, b, h, q, k0 + t * 16 + 4 * g + r) : e;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + t * 16 + 4 * g + r;
+                        if (key >= p.Tk || (p.causal && key > q + coff)) s[u][t][r] = -INFINITY;
+                    }
             }
-        l = l * alpha + group_sum(rs);
-        m = mn;
+            float mx = -INFINITY;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[u][t][r]);
+            mx = group_max(mx);
+            const float mn = fmaxf(m[u], mx * mul);
+            const float alpha = fast_exp2(m[u] - mn);
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp2(fmaf(s[u][t][r], mul, -mn));
+                    rs += e;
+                    s[u][t][r] = p.drop_p > 0.f ? e * ATT_DROP(p, b, h, q, k0 + t * 16 + 4 * g + r) : e;
+                }
+            l[u] = l[u] * alpha + group_sum(rs);
+            m[u] = mn;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[u][dt] *= alpha;
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {        // two 32-key reduction steps
-            const bf16x8_t pf = pack_pair(s[2 * st], s[2 * st + 1]);
+            bf16x8_t vfr[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sV, st * 32, st * 32 + 16, dt * 16, lane), pf,
-                                                                 o[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) vfr[dt] = frag_tr(tV, st * 32, st * 32 + 16, dt * 16, lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bf16x8_t pf = pack_pair(s[u][2 * st], s[u][2 * st + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf, o[u][dt], 0, 0, 0);
+            }
         }
+        if (more) {
+            tile_store(sK[buf ^ 1], rk, tid);
+            tile_store(sV[buf ^ 1], rv, tid);
+        }
+        __syncthreads();       // next tile published; everyone is done with this one before it is overwritten next round
+        buf ^= 1;
     }
-    if (q < p.Tq) {
-        const float inv = 1.f / l;
-        bf16_t* Op = reinterpret_cast<bf16_t*>(p.O) + b * p.o_bs + (long long)q * p.o_ld + h * 64;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 pk = make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
-            *reinterpret_cast<uint2*>(Op + dt * 16 + 4 * g) = pk;
+    for (int u = 0; u < U; ++u) {
+        const int q = qw0 + u * 16 + i16;
+        if (q < p.Tq) {
+            const float inv = 1.f / l[u];
+            bf16_t* Op = reinterpret_cast<bf16_t*>(p.O) + b * p.o_bs + (long long)q * p.o_ld + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk = make_uint2(pack_bf2(o[u][dt][0] * inv, o[u][dt][1] * inv), pack_bf2(o[u][dt][2] * inv, o[u][dt][3] * inv));
+                *reinterpret_cast<uint2*>(Op + dt * 16 + 4 * g) = pk;
+            }
+            if (g == 0) p.lse[((long long)b * p.H + h) * p.Tq + q] = m[u] * SMX_LN2 + __logf(l[u]);   // natural-log units
         }
-        if (g == 0) p.lse[((long long)b * p.H + h) * p.Tq + q] = m + __logf(l);
     }
 }
 
-// dQ: block owns 64 queries (wave: 16), loops over key tiles.
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16(SmxAttnParams p) {
-    __shared__ __attribute__((aligned(16))) char sK[8192];
-    __shared__ __attribute__((aligned(16))) char sV[8192];
+// dQ: block owns 64 U queries (wave: U x 16), loops over key tiles.  Also produces delta = rowsum(dO * O) for the
+// dK/dV kernel that follows it on the stream.
+template <int U>
+__global__ __launch_bounds__(256, U == 1 ? 3 : 1) void attn_bwd_dq_bf16(SmxAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sK[2][8192];
+    __shared__ __attribute__((aligned(16))) char sV[2][8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, q = blockIdx.x * 64 + wave * 16 + i16;
+    const int b = blockIdx.z, h = blockIdx.y, qw0 = blockIdx.x * (64 * U) + wave * (16 * U);
     const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * 64;
     const bf16_t* dOp = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * 64;
+    const bf16_t* Op = reinterpret_cast<const bf16_t*>(p.O) + b * p.o_bs + h * 64;
     const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * 64;
     const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * 64;
-    bf16x8_t qf[2], dof[2];
+    bf16x8_t qf[U][2], dof[U][2];
+    float nlse2[U], delta[U];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        union { bf16x8_t v; uint4 u; } f, d;
-        f.u = d.u = make_uint4(0, 0, 0, 0);
-        if (q < p.Tq) {
-            f.u = *reinterpret_cast<const uint4*>(Qp + (long long)q * p.q_ld + kk * 32 + g * 8);
-            d.u = *reinterpret_cast<const uint4*>(dOp + (long long)q * p.do_ld + kk * 32 + g * 8);
+    for (int u = 0; u < U; ++u) {
+        const int q = qw0 + u * 16 + i16;
+        float dsum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[u][kk] = load_row_frag(Qp, p.q_ld, q, p.Tq, kk, g);
+            dof[u][kk] = load_row_frag(dOp, p.do_ld, q, p.Tq, kk, g);
+            if (q < p.Tq) {
+                float ov[8], dv[8];
+                load8(Op + (long long)q * p.o_ld + kk * 32 + g * 8, ov);
+                load8(dOp + (long long)q * p.do_ld + kk * 32 + g * 8, dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dsum = fmaf(ov[e], dv[e], dsum);
+            }
         }
-        qf[kk] = f.v;
-        dof[kk] = d.v;
+        delta[u] = group_sum(dsum);
+        nlse2[u] = 0.f;
+        if (q < p.Tq) {
+            const long long li = ((long long)b * p.H + h) * p.Tq + q;
+            nlse2[u] = -p.lse[li] * SMX_LOG2E;
+            if (g == 0) p.delta[li] = delta[u];
+        }
     }
-    float lse = 0.f, delta = 0.f;
-    if (q < p.Tq) {
-        lse = p.lse[((long long)b * p.H + h) * p.Tq + q];
-        delta = p.delta[((long long)b * p.H + h) * p.Tq + q];
-    }
-    f32x4_t dq[4] = {ZERO4, ZERO4, ZERO4, ZERO4};
+    f32x4_t dq[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[u][dt] = ZERO4;
+    const float sl2 = p.scale * SMX_LOG2E;
     const int coff = p.Tk - p.Tq;
     int kend = p.Tk;
-    if (p.causal) kend = min(p.Tk, blockIdx.x * 64 + 64 + coff);
+    if (p.causal) kend = min(p.Tk, (int)blockIdx.x * (64 * U) + 64 * U + coff);
+    uint4 rk[2], rv[2];
+    tile_load(rk, Kp, p.k_ld, 0, p.Tk, tid);
+    tile_load(rv, Vp, p.v_ld, 0, p.Tk, tid);
+    tile_store(sK[0], rk, tid);
+    tile_store(sV[0], rv, tid);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = 0; k0 < kend; k0 += 64) {
-        __syncthreads();
-        stage_tile(sK, Kp, p.k_ld, k0, p.Tk, tid);
-        stage_tile(sV, Vp, p.v_ld, k0, p.Tk, tid);
-        __syncthreads();
-        f32x4_t ds[4];
+        const bool more = k0 + 64 < kend;
+        if (more) {
+            tile_load(rk, Kp, p.k_ld, k0 + 64, p.Tk, tid);
+            tile_load(rv, Vp, p.v_ld, k0 + 64, p.Tk, tid);
+        }
+        const char* tK = sK[buf];
+        const char* tV = sV[buf];
+        const bool masked = (k0 + 64 > p.Tk) || ((int)blockIdx.x * (64 * U) + 64 * U > p.Tq) ||
+                            (p.causal && k0 + 63 > (int)blockIdx.x * (64 * U) + coff);
+        f32x4_t ds[U][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            f32x4_t s = ZERO4, dp = ZERO4;
+            const bf16x8_t k0f = frag_kc(tK, t * 16, 0, lane), k1f = frag_kc(tK, t * 16, 1, lane);
+            const bf16x8_t v0f = frag_kc(tV, t * 16, 0, lane), v1f = frag_kc(tV, t * 16, 1, lane);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sK, t * 16, kk, lane), qf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sV, t * 16, kk, lane), dof[kk], dp, 0, 0, 0);
-            }
+            for (int u = 0; u < U; ++u) {
+                const int q = qw0 + u * 16 + i16;
+                f32x4_t sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0f, qf[u][0], ZERO4, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[u][1], sc, 0, 0, 0);
+                f32x4_t dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0f, dof[u][0], ZERO4, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1f, dof[u][1], dp, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + t * 16 + 4 * g + r;
-                float v = s[r] * p.scale;
-                if (p.bias && q < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + q) * p.Tk + key];
-                float pr = __expf(v - lse);
-                if (key >= p.Tk || q >= p.Tq || (p.causal && key > q + coff)) pr = 0.f;
-                const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, q, key) : 1.f;
-                ds[t][r] = pr * (dm * dp[r] - delta);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + t * 16 + 4 * g + r;
+                    float off = nlse2[u];
+                    if (p.bias && q < p.Tq && key < p.Tk) off = fmaf(p.bias[((long long)h * p.Tq + q) * p.Tk + key], SMX_LOG2E, off);
+                    float pr = fast_exp2(fmaf(sc[r], sl2, off));
+                    if (masked && (key >= p.Tk || q >= p.Tq || (p.causal && key > q + coff))) pr = 0.f;
+                    const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, q, key) : 1.f;
+                    ds[u][t][r] = pr * (dm * dp[r] - delta[u]);
+                }
             }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            const bf16x8_t pf = pack_pair(ds[2 * st], ds[2 * st + 1]);
+            bf16x8_t kfr[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sK, st * 32, st * 32 + 16, dt * 16, lane), pf,
-                                                                  dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < 4; ++dt) kfr[dt] = frag_tr(tK, st * 32, st * 32 + 16, dt * 16, lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bf16x8_t pf = pack_pair(ds[u][2 * st], ds[u][2 * st + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[dt], pf, dq[u][dt], 0, 0, 0);
+            }
         }
+        if (more) {
+            tile_store(sK[buf ^ 1], rk, tid);
+            tile_store(sV[buf ^ 1], rv, tid);
+        }
+        __syncthreads();
+        buf ^= 1;
     }
-    if (q < p.Tq) {
-        bf16_t* dQp = reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + (long long)q * p.dq_ld + h * 64;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 pk = make_uint2(pack_bf2(dq[dt][0] * p.scale, dq[dt][1] * p.scale),
-                                  pack_bf2(dq[dt][2] * p.scale, dq[dt][3] * p.scale));
-            *reinterpret_cast<uint2*>(dQp + dt * 16 + 4 * g) = pk;
+    for (int u = 0; u < U; ++u) {
+        const int q = qw0 + u * 16 + i16;
+        if (q < p.Tq) {
+            bf16_t* dQp = reinterpret_cast<bf16_t*>(p.dQ) + b * p.dq_bs + (long long)q * p.dq_ld + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk = make_uint2(pack_bf2(dq[u][dt][0] * p.scale, dq[u][dt][1] * p.scale),
+                                      pack_bf2(dq[u][dt][2] * p.scale, dq[u][dt][3] * p.scale));
+                *reinterpret_cast<uint2*>(dQp + dt * 16 + 4 * g) = pk;
+            }
         }
     }
 }
 
-// dK/dV: block owns 64 keys (wave: 16), loops over query tiles.  Scores are produced UN-transposed here
+// dK/dV: block owns 64 U keys (wave: U x 16), loops over 64-query tiles.  Scores are produced UN-transposed here
 // (S = Q K^T: lane owns one key column) so that P and dS are again directly the B operand of the
 // reductions over queries.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16(SmxAttnParams p) {
-    __shared__ __attribute__((aligned(16))) char sQ[8192];
-    __shared__ __attribute__((aligned(16))) char sDO[8192];
-    __shared__ float sLse[64];
-    __shared__ float sDelta[64];
+template <int U>
+__global__ __launch_bounds__(256, U == 1 ? 2 : 1) void attn_bwd_dkv_bf16(SmxAttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sQ[2][8192];
+    __shared__ __attribute__((aligned(16))) char sDO[2][8192];
+    __shared__ float sNlse2[2][64];
+    __shared__ float sDelta[2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, key = blockIdx.x * 64 + wave * 16 + i16;
+    const int b = blockIdx.z, h = blockIdx.y, kw0 = blockIdx.x * (64 * U) + wave * (16 * U);
     const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q) + b * p.q_bs + h * 64;
     const bf16_t* dOp = reinterpret_cast<const bf16_t*>(p.dO) + b * p.do_bs + h * 64;
     const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K) + b * p.k_bs + h * 64;
     const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.V) + b * p.v_bs + h * 64;
-    bf16x8_t kf[2], vf[2];
+    const long long rowbase = ((long long)b * p.H + h) * p.Tq;
+    bf16x8_t kf[U][2], vf[U][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        union { bf16x8_t v; uint4 u; } f, d;
-        f.u = d.u = make_uint4(0, 0, 0, 0);
-        if (key < p.Tk) {
-            f.u = *reinterpret_cast<const uint4*>(Kp + (long long)key * p.k_ld + kk * 32 + g * 8);
-            d.u = *reinterpret_cast<const uint4*>(Vp + (long long)key * p.v_ld + kk * 32 + g * 8);
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[u][kk] = load_row_frag(Kp, p.k_ld, kw0 + u * 16 + i16, p.Tk, kk, g);
+            vf[u][kk] = load_row_frag(Vp, p.v_ld, kw0 + u * 16 + i16, p.Tk, kk, g);
         }
-        kf[kk] = f.v;
-        vf[kk] = d.v;
-    }
-    f32x4_t dk[4] = {ZERO4, ZERO4, ZERO4, ZERO4}, dv[4] = {ZERO4, ZERO4, ZERO4, ZERO4};
+    f32x4_t dk[U][4], dv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[u][dt] = dv[u][dt] = ZERO4;
+    const float sl2 = p.scale * SMX_LOG2E;
     const int coff = p.Tk - p.Tq;
     int qbeg = 0;
-    if (p.causal) qbeg = max(0, (int)(blockIdx.x * 64) - coff) & ~63;   // queries before this see none of the block's keys
+    if (p.causal) qbeg = max(0, (int)(blockIdx.x * (64 * U)) - coff) & ~63;   // queries before this see none of the block's keys
+    uint4 rq[2], rd[2];
+    float rl = 0.f, rdl = 0.f;
+    tile_load(rq, Qp, p.q_ld, qbeg, p.Tq, tid);
+    tile_load(rd, dOp, p.do_ld, qbeg, p.Tq, tid);
+    tile_store(sQ[0], rq, tid);
+    tile_store(sDO[0], rd, tid);
+    if (tid < 64) {
+        const int qq = qbeg + tid;
+        sNlse2[0][tid] = qq < p.Tq ? -p.lse[rowbase + qq] * SMX_LOG2E : 0.f;
+        sDelta[0][tid] = qq < p.Tq ? p.delta[rowbase + qq] : 0.f;
+    }
+    __syncthreads();
+    int buf = 0;
     for (int q0 = qbeg; q0 < p.Tq; q0 += 64) {
-        __syncthreads();
-        stage_tile(sQ, Qp, p.q_ld, q0, p.Tq, tid);
-        stage_tile(sDO, dOp, p.do_ld, q0, p.Tq, tid);
-        if (tid < 64) {
-            const int qq = q0 + tid;
-            sLse[tid] = qq < p.Tq ? p.lse[((long long)b * p.H + h) * p.Tq + qq] : 0.f;
-            sDelta[tid] = qq < p.Tq ? p.delta[((long long)b * p.H + h) * p.Tq + qq] : 0.f;
+        const bool more = q0 + 64 < p.Tq;
+        if (more) {
+            tile_load(rq, Qp, p.q_ld, q0 + 64, p.Tq, tid);
+            tile_load(rd, dOp, p.do_ld, q0 + 64, p.Tq, tid);
+            if (tid < 64) {
+                const int qq = q0 + 64 + tid;
+                rl = qq < p.Tq ? -p.lse[rowbase + qq] * SMX_LOG2E : 0.f;
+                rdl = qq < p.Tq ? p.delta[rowbase + qq] : 0.f;
+            }
         }
-        __syncthreads();
-        f32x4_t pt[4], ds[4];
+        const char* tQ = sQ[buf];
+        const char* tDO = sDO[buf];
+        const bool masked = (q0 + 64 > p.Tq) || ((int)blockIdx.x * (64 * U) + 64 * U > p.Tk) ||
+                            (p.causal && (int)blockIdx.x * (64 * U) + 64 * U - 1 > q0 + coff);
+        f32x4_t pt[U][4], ds[U][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {          // 16-query sub-tiles: D rows = queries 4g+r, cols = keys
-            f32x4_t s = ZERO4, dp = ZERO4;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sQ, t * 16, kk, lane), kf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_kc(sDO, t * 16, kk, lane), vf[kk], dp, 0, 0, 0);
-            }
+            const bf16x8_t q0f = frag_kc(tQ, t * 16, 0, lane), q1f = frag_kc(tQ, t * 16, 1, lane);
+            const bf16x8_t d0f = frag_kc(tDO, t * 16, 0, lane), d1f = frag_kc(tDO, t * 16, 1, lane);
+            float nl[4], dl[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ql = t * 16 + 4 * g + r, qq = q0 + ql;
-                float v = s[r] * p.scale;
-                if (p.bias && qq < p.Tq && key < p.Tk) v += p.bias[((long long)h * p.Tq + qq) * p.Tk + key];
-                float pr = __expf(v - sLse[ql]);
-                if (qq >= p.Tq || key >= p.Tk || (p.causal && key > qq + coff)) pr = 0.f;
-                const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, qq, key) : 1.f;
-                pt[t][r] = pr * dm;
-                ds[t][r] = pr * (dm * dp[r] - sDelta[ql]);
+                nl[r] = sNlse2[buf][t * 16 + 4 * g + r];
+                dl[r] = sDelta[buf][t * 16 + 4 * g + r];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int key = kw0 + u * 16 + i16;
+                f32x4_t sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[u][0], ZERO4, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[u][1], sc, 0, 0, 0);
+                f32x4_t dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[u][0], ZERO4, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[u][1], dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = q0 + t * 16 + 4 * g + r;
+                    float off = nl[r];
+                    if (p.bias && qq < p.Tq && key < p.Tk) off = fmaf(p.bias[((long long)h * p.Tq + qq) * p.Tk + key], SMX_LOG2E, off);
+                    float pr = fast_exp2(fmaf(sc[r], sl2, off));
+                    if (masked && (qq >= p.Tq || key >= p.Tk || (p.causal && key > qq + coff))) pr = 0.f;
+                    const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, qq, key) : 1.f;
+                    pt[u][t][r] = pr * dm;
+                    ds[u][t][r] = pr * (dm * dp[r] - dl[r]);
+                }
             }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {       // two 32-query reduction steps
-            const bf16x8_t pf = pack_pair(pt[2 * st], pt[2 * st + 1]);
-            const bf16x8_t df = pack_pair(ds[2 * st], ds[2 * st + 1]);
+            bf16x8_t dfr[4], qfr[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sDO, st * 32, st * 32 + 16, dt * 16, lane), pf,
-                                                                  dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(sQ, st * 32, st * 32 + 16, dt * 16, lane), df,
-                                                                  dk[dt], 0, 0, 0);
+                dfr[dt] = frag_tr(tDO, st * 32, st * 32 + 16, dt * 16, lane);
+                qfr[dt] = frag_tr(tQ, st * 32, st * 32 + 16, dt * 16, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bf16x8_t pf = pack_pair(pt[u][2 * st], pt[u][2 * st + 1]);
+                const bf16x8_t df = pack_pair(ds[u][2 * st], ds[u][2 * st + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[dt], pf, dv[u][dt], 0, 0, 0);
+                    dk[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[dt], df, dk[u][dt], 0, 0, 0);
+                }
             }
         }
+        if (more) {
+            tile_store(sQ[buf ^ 1], rq, tid);
+            tile_store(sDO[buf ^ 1], rd, tid);
+            if (tid < 64) {
+                sNlse2[buf ^ 1][tid] = rl;
+                sDelta[buf ^ 1][tid] = rdl;
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
     }
-    if (key < p.Tk) {
-        bf16_t* dKp = reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + (long long)key * p.dk_ld + h * 64;
-        bf16_t* dVp = reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + (long long)key * p.dv_ld + h * 64;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            *reinterpret_cast<uint2*>(dKp + dt * 16 + 4 * g) =
-                make_uint2(pack_bf2(dk[dt][0] * p.scale, dk[dt][1] * p.scale), pack_bf2(dk[dt][2] * p.scale, dk[dt][3] * p.scale));
-            *reinterpret_cast<uint2*>(dVp + dt * 16 + 4 * g) =
-                make_uint2(pack_bf2(dv[dt][0], dv[dt][1]), pack_bf2(dv[dt][2], dv[dt][3]));
+    for (int u = 0; u < U; ++u) {
+        const int key = kw0 + u * 16 + i16;
+        if (key < p.Tk) {
+            bf16_t* dKp = reinterpret_cast<bf16_t*>(p.dK) + b * p.dk_bs + (long long)key * p.dk_ld + h * 64;
+            bf16_t* dVp = reinterpret_cast<bf16_t*>(p.dV) + b * p.dv_bs + (long long)key * p.dv_ld + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<uint2*>(dKp + dt * 16 + 4 * g) =
+                    make_uint2(pack_bf2(dk[u][dt][0] * p.scale, dk[u][dt][1] * p.scale),
+                               pack_bf2(dk[u][dt][2] * p.scale, dk[u][dt][3] * p.scale));
+                *reinterpret_cast<uint2*>(dVp + dt * 16 + 4 * g) =
+                    make_uint2(pack_bf2(dv[u][dt][0], dv[u][dt][1]), pack_bf2(dv[u][dt][2], dv[u][dt][3]));
+            }
         }
     }
 }
@@ -472,7 +651,9 @@ extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t
         const int n = p.B * p.H * p.Tq;
         hipLaunchKernelGGL(attn_fwd_simple<bf16_t>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
     } else if (dtype == SMX_BF16) {
-        hipLaunchKernelGGL(attn_fwd_bf16, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        // U = 1 (16 queries per wave): measured faster than U = 2 at T = 499 (occupancy 4 vs 2 waves/SIMD; the
+        // kernels are VALU-bound on the softmax, not LDS-bound)
+        hipLaunchKernelGGL(attn_fwd_bf16<1>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
     } else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
@@ -496,9 +677,10 @@ extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t
         hipLaunchKernelGGL(attn_bwd_dkv_simple<bf16_t>, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
     } else if (dtype == SMX_BF16) {
         if (p.dbias) return SMX_EINVAL;
-        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(attn_bwd_dq_bf16, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_bf16, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        if (!p.O) return SMX_EINVAL;
+        // dQ also writes delta = rowsum(dO * O); the dK/dV kernel reads it (stream order)
+        hipLaunchKernelGGL(attn_bwd_dq_bf16<1>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_bf16<1>, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
     } else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
