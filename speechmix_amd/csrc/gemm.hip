@@ -400,11 +400,9 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
         if (aux_in) {
             float a[8];
             load8(aux_in + sb, a);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] *= act_grad(a[e], p.act);
+            act_grad_mul8(x, a, p.act);
         } else if (p.act) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = act_fwd(x[e], p.act);
+            act_fwd8(x, p.act);
         }
         if (p.drop_p > 0.f) {
             const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
@@ -463,8 +461,12 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
     const int rr = lane >> 3, cc = lane & 7;
     const int n = nw0 + cc * 8;
     float bs[8];
+    if (p.bias && n + 8 <= p.N && !((zbias + n) & 3)) {
+        load8(p.bias + zbias + n, bs);                 // two 16-B loads, in flight while the first half is transposed
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bs[e] = (p.bias && n + e < p.N) ? p.bias[zbias + n + e] : 0.f;
+        for (int e = 0; e < 8; ++e) bs[e] = (p.bias && n + e < p.N) ? p.bias[zbias + n + e] : 0.f;
+    }
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
 #pragma unroll

@@ -89,13 +89,73 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     return x;
 }
 __device__ __forceinline__ float act_grad(float x, int act) {
-    if (act == SMX_ACT_GELU) {
-        const float cdf = 0.5f * (1.0f + smx_erf(x * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-        return cdf + x * pdf;
+    if (act == SMX_ACT_GELU) {       // erf(x/sqrt2) and the pdf share one exponential E = exp(-x^2/2)
+        const float ax = fabsf(x);
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+        float poly = fmaf(1.061405429f, t, -1.453152027f);
+        poly = fmaf(poly, t, 1.421413741f);
+        poly = fmaf(poly, t, -0.284496736f);
+        poly = fmaf(poly, t, 0.254829592f);
+        const float E = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.44269504088896340736f));
+        const float er = copysignf(1.0f - poly * t * E, x);
+        return fmaf(er, 0.5f, 0.5f) + x * 0.39894228040143267794f * E;
     }
     if (act == SMX_ACT_RELU) return x > 0.f ? 1.f : 0.f;
     return 1.f;
+}
+
+// ---- the same two functions on 8 values with packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 process two values per
+// instruction at full rate; the activation epilogues are VALU-bound).  erf(x/sqrt2) and the Gaussian pdf share ONE
+// exponential E = exp(-x^2/2): erf = 1 - poly(t) t E (A&S 7.1.26 at z = |x|/sqrt2), pdf = E / sqrt(2 pi).
+typedef __attribute__((ext_vector_type(2))) float smx_f2;
+#define SMX_PK(v) ((smx_f2){(v), (v)})
+__device__ __forceinline__ void smx_erf_e2(smx_f2 x, smx_f2& erfv, smx_f2& E) {
+    const smx_f2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const smx_f2 d = __builtin_elementwise_fma(SMX_PK(0.3275911f * 0.70710678118654752440f), ax, SMX_PK(1.0f));
+    const smx_f2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    smx_f2 poly = __builtin_elementwise_fma(SMX_PK(1.061405429f), t, SMX_PK(-1.453152027f));
+    poly = __builtin_elementwise_fma(poly, t, SMX_PK(1.421413741f));
+    poly = __builtin_elementwise_fma(poly, t, SMX_PK(-0.284496736f));
+    poly = __builtin_elementwise_fma(poly, t, SMX_PK(0.254829592f));
+    const smx_f2 arg = x * x * SMX_PK(-0.5f * 1.44269504088896340736f);
+    E = (smx_f2){__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+    const smx_f2 r = __builtin_elementwise_fma(-(poly * t), E, SMX_PK(1.0f));
+    erfv = (smx_f2){copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+}
+__device__ __forceinline__ void act_fwd8(float x[8], int act) {
+    if (act == SMX_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const smx_f2 v = {x[e], x[e + 1]};
+            smx_f2 er, E;
+            smx_erf_e2(v, er, E);
+            const smx_f2 hx = v * SMX_PK(0.5f);
+            const smx_f2 y = __builtin_elementwise_fma(hx, er, hx);
+            x[e] = y[0];
+            x[e + 1] = y[1];
+        }
+    } else if (act == SMX_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+    }
+}
+// x[e] *= act'(pre[e])
+__device__ __forceinline__ void act_grad_mul8(float x[8], const float pre[8], int act) {
+    if (act == SMX_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const smx_f2 v = {pre[e], pre[e + 1]};
+            smx_f2 er, E;
+            smx_erf_e2(v, er, E);
+            const smx_f2 cdf = __builtin_elementwise_fma(er, SMX_PK(0.5f), SMX_PK(0.5f));
+            const smx_f2 gr = __builtin_elementwise_fma(v * SMX_PK(0.39894228040143267794f), E, cdf);
+            x[e] *= gr[0];
+            x[e + 1] *= gr[1];
+        }
+    } else if (act == SMX_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = pre[e] > 0.f ? x[e] : 0.f;
+    }
 }
 
 // ---- counter-based dropout: keep(idx) is a pure function of (seed, element index), so backward regenerates
