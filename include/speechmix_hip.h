@@ -74,7 +74,9 @@ int smx_attention_bwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
 typedef struct SmxConv0Params {
     const float *wave, *w, *cbias, *gamma, *beta; double* stats; void* y; const void* dy; double* bstats;
     float *dw, *dcbias, *dgamma, *dbeta; int B, N, C, k, stride, T0, group; float eps; int tiles_per_block;
+    float* partials; int nb;   /* partials: caller workspace of smx_conv0_workspace_floats(B, C, k) floats; nb: set by the launchers */
 } SmxConv0Params;
+long long smx_conv0_workspace_floats(int B, int C, int k);
 int smx_conv0_fwd(const SmxConv0Params* p, int dtype, hipStream_t stream);
 int smx_conv0_bwd(const SmxConv0Params* p, int dtype, hipStream_t stream);
 

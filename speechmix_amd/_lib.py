@@ -84,7 +84,7 @@ class Conv0Params(C.Structure):
                 ("bstats", C.c_void_p), ("dw", C.c_void_p), ("dcbias", C.c_void_p), ("dgamma", C.c_void_p),
                 ("dbeta", C.c_void_p),
                 ("B", C.c_int), ("N", C.c_int), ("C", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("T0", C.c_int),
-                ("group", C.c_int), ("eps", C.c_float), ("tiles_per_block", C.c_int)]
+                ("group", C.c_int), ("eps", C.c_float), ("tiles_per_block", C.c_int), ("partials", C.c_void_p), ("nb", C.c_int)]
 
 
 class CEParams(C.Structure):

@@ -3,14 +3,21 @@
 // (TF:models/wav2vec2/modeling_wav2vec2.py:301-323), or emitted plain for the "layer" extractor variant
 // (conv(+bias) -> LayerNorm over C -> GELU, :275-299; the LN+GELU is smx_norm_fwd with act=GELU).
 //
-// HBM-bound: C_in = 1 so the 10-tap conv is recomputed from the waveform (0.64 MB / 10 s clip, LDS-staged)
-// instead of ever being stored; the only large traffic is the channels-last output [B, T0, C]
-// (32.8 MB / clip in bf16), written once with 16-B stores.  Statistics are accumulated in fp64 atomics.
-// Thread <-> 8 consecutive channels, wave <-> time steps.
+// C_in = 1, so the 10-tap conv is recomputed from the waveform (0.64 MB / 10 s clip, LDS-staged, broadcast reads)
+// instead of ever being stored; the only large traffic is the channels-last activation [B, T0, C] (32.8 MB / clip in
+// bf16), written once (forward) and read twice (backward).  What is left is VALU work - 10 FMAs + GroupNorm + GELU per
+// output element - so the kernels are built for the vector unit:
+//   * thread <-> one PAIR of channels, every op a packed-fp32 instruction (v_pk_fma_f32: two channels per issue);
+//     the whole block walks the same time steps, so the waveform window is an LDS broadcast;
+//   * exact tap count (template K = 10; a zero-padded 16-tap instance covers other kernels);
+//   * 20 weight + 20 gradient-accumulator registers per thread instead of 256: high occupancy, no spills;
+//   * reductions over time are register-resident per block and leave the block as ONE partial row
+//     (no atomics - device-scope atomics serialise in L2); a second tiny pass sums the partial rows.
 #include "smx_common.h"
 
 #define C0_MAXK 16
-#define C0_TT 64     // time steps per block
+#define C0_TT 64        // time steps per LDS stage
+#define C0_NBMAX 64     // reduction kernels: at most this many blocks (partial rows) per clip
 
 struct SmxConv0Params {
     const float* wave;    // [B, N] fp32
@@ -22,24 +29,38 @@ struct SmxConv0Params {
     void* y;              // [B, T0, C] output (dtype T)
     const void* dy;       // backward: grad wrt output [B, T0, C]
     double* bstats;       // backward: [B, C, 2]  sum dz, sum dz*xhat
-    float* dw;            // [C, k] fp32 (atomic)
+    float* dw;            // [C, k] fp32 (accumulated)
     float* dcbias;        // [C] or null (plain mode)
     float* dgamma;        // [C]
     float* dbeta;
     int B, N, C, k, stride, T0;
     int group;            // 1: GroupNorm+GELU fused, 0: plain conv
     float eps;
-    int tiles_per_block;  // set by the launchers: consecutive time tiles handled by one block (reduction kernels)
+    int tiles_per_block;  // set by the launchers
+    float* partials;      // workspace, >= smx_conv0_workspace_floats(B, C, k) floats (reduction kernels)
+    int nb;               // set by the launchers: blocks per clip in the reduction kernels
 };
 
-__device__ __forceinline__ void load_w8(const SmxConv0Params& p, int c0, float w[8][C0_MAXK], float cb[8]) {
+extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream);
+
+extern "C" long long smx_conv0_workspace_floats(int B, int C, int k) { return (long long)B * C0_NBMAX * C * (k + 2); }
+
+template <int K>
+struct C0Thread {
+    smx_f2 w[K];
+    smx_f2 cb;
+    __device__ __forceinline__ void load(const SmxConv0Params& p, int c0) {
+        cb = p.cbias ? (smx_f2){p.cbias[c0], p.cbias[c0 + 1]} : SMX_PK(0.f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        cb[j] = p.cbias ? p.cbias[c0 + j] : 0.f;
-#pragma unroll
-        for (int t = 0; t < C0_MAXK; ++t) w[j][t] = t < p.k ? p.w[(c0 + j) * p.k + t] : 0.f;
+        for (int t = 0; t < K; ++t) w[t] = t < p.k ? (smx_f2){p.w[c0 * p.k + t], p.w[(c0 + 1) * p.k + t]} : SMX_PK(0.f);
     }
-}
+    __device__ __forceinline__ smx_f2 conv(const float* x) const {
+        smx_f2 u = cb;
+#pragma unroll
+        for (int t = 0; t < K; ++t) u = __builtin_elementwise_fma(w[t], SMX_PK(x[t]), u);
+        return u;
+    }
+};
 
 __device__ __forceinline__ void stage_wave(const SmxConv0Params& p, float* sx, int b, int t0) {
     const int n0 = t0 * p.stride, cnt = C0_TT * p.stride + C0_MAXK;
@@ -48,158 +69,157 @@ __device__ __forceinline__ void stage_wave(const SmxConv0Params& p, float* sx, i
         sx[i] = n < p.N ? p.wave[(long long)b * p.N + n] : 0.f;
     }
 }
+// GroupNorm of channel pair (c0, c0+1) of clip b as z = u * a + b0, xhat = u * rs + xo
+struct C0Norm {
+    smx_f2 a, b0, rs, xo;
+    __device__ __forceinline__ void load(const SmxConv0Params& p, int b, int c0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double s = p.stats[((long long)b * p.C + c0 + j) * 2], q = p.stats[((long long)b * p.C + c0 + j) * 2 + 1];
+            const double m = s / p.T0;
+            double var = q / p.T0 - m * m;
+            if (var < 0) var = 0;
+            const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float g = p.gamma[c0 + j];
+            rs[j] = rstd;
+            xo[j] = -mean * rstd;
+            a[j] = rstd * g;
+            b0[j] = p.beta[c0 + j] - mean * rstd * g;
+        }
+    }
+};
+__device__ __forceinline__ smx_f2 gelu2(smx_f2 z) {
+    smx_f2 er, E;
+    smx_erf_e2(z, er, E);
+    const smx_f2 hz = z * SMX_PK(0.5f);
+    return __builtin_elementwise_fma(hz, er, hz);
+}
+__device__ __forceinline__ smx_f2 gelu_grad2(smx_f2 z) {
+    smx_f2 er, E;
+    smx_erf_e2(z, er, E);
+    const smx_f2 cdf = __builtin_elementwise_fma(er, SMX_PK(0.5f), SMX_PK(0.5f));
+    return __builtin_elementwise_fma(z * SMX_PK(0.39894228040143267794f), E, cdf);
+}
+__device__ __forceinline__ smx_f2 load_pair(const float* p) { const float2 v = *reinterpret_cast<const float2*>(p); return (smx_f2){v.x, v.y}; }
+__device__ __forceinline__ smx_f2 load_pair(const bf16_t* p) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    return (smx_f2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ void store_pair(float* p, smx_f2 v) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+__device__ __forceinline__ void store_pair(bf16_t* p, smx_f2 v) { *reinterpret_cast<unsigned*>(p) = pack_bf2(v[0], v[1]); }
 
-// pass 1 (group mode): per-(b,c) sum / sumsq of u = conv(x).  A block walks `tiles_per_block` time tiles with
-// register accumulators, reduces its 4 waves through LDS and issues ONE fp64 atomic pair per channel.
+// pass 1 (group mode): per-(b,c) sum / sumsq of u = conv(x): one partial row [C][2] per block
+template <int K>
 __global__ __launch_bounds__(256) void conv0_stats_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
-    __shared__ float red[4][64][16];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c0 = lane * 8;
+    const int b = blockIdx.y, c0 = threadIdx.x * 2;
+    const bool active = c0 < p.C;
     const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
     const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
-    float s[8], q[8], w[8][C0_MAXK], cb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    if (c0 < p.C) load_w8(p, c0, w, cb);
+    C0Thread<K> th;
+    if (active) th.load(p, c0);
+    smx_f2 s = SMX_PK(0.f), q = SMX_PK(0.f);
     for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
         const int t0 = tile * C0_TT;
         __syncthreads();
         stage_wave(p, sx, b, t0);
         __syncthreads();
-        if (c0 < p.C) {
-            for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
-                const float* x = sx + tt * p.stride;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float u = cb[j];
-#pragma unroll
-                    for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
-                    s[j] += u;
-                    q[j] += u * u;
-                }
+        if (active) {
+            const int ntt = min(C0_TT, p.T0 - t0);
+            smx_f2 st = SMX_PK(0.f), qt = SMX_PK(0.f);          // per-tile sums, then a second level (rounding)
+            for (int tt = 0; tt < ntt; ++tt) {
+                const smx_f2 u = th.conv(sx + tt * p.stride);
+                st += u;
+                qt = __builtin_elementwise_fma(u, u, qt);
             }
+            s += st;
+            q += qt;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { red[wv][lane][j] = s[j]; red[wv][lane][8 + j] = q[j]; }
-    __syncthreads();
-    if (wv == 0 && c0 < p.C) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float ss = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
-            const float qq = red[0][lane][8 + j] + red[1][lane][8 + j] + red[2][lane][8 + j] + red[3][lane][8 + j];
-            atomicAdd(p.stats + ((long long)b * p.C + c0 + j) * 2, (double)ss);
-            atomicAdd(p.stats + ((long long)b * p.C + c0 + j) * 2 + 1, (double)qq);
-        }
-    }
+    if (active)
+        *reinterpret_cast<float4*>(p.partials + (((long long)b * p.nb + blockIdx.x) * p.C + c0) * 2) = make_float4(s[0], q[0], s[1], q[1]);
 }
-
-__device__ __forceinline__ void mean_rstd(const SmxConv0Params& p, int b, int c, float& mean, float& rstd) {
-    const double s = p.stats[((long long)b * p.C + c) * 2], q = p.stats[((long long)b * p.C + c) * 2 + 1];
-    const double m = s / p.T0;
-    double var = q / p.T0 - m * m;
-    if (var < 0) var = 0;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+// dst[b][c][0..1] (fp64) = sum over the clip's partial rows
+__global__ void conv0_stats_finalize_kernel(const float* __restrict__ partials, double* __restrict__ dst, int B, int C, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (b, c, j)
+    if (i >= B * C * 2) return;
+    const int b = i / (C * 2), r = i - b * C * 2;
+    double a = 0;
+    for (int k = 0; k < nb; ++k) a += (double)partials[((long long)b * nb + k) * C * 2 + r];
+    dst[i] = a;
 }
 
 // pass 2: y = GELU(gamma * (u - mean) * rstd + beta)  (group)   or   y = u  (plain)
-template <typename T>
+template <typename T, int K>
 __global__ __launch_bounds__(256) void conv0_apply_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
-    const int b = blockIdx.y, t0 = blockIdx.x * C0_TT;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    stage_wave(p, sx, b, t0);
-    __syncthreads();
-    T* Y = reinterpret_cast<T*>(p.y) + (long long)b * p.T0 * p.C;
-    const int c0 = lane * 8;
-    if (c0 >= p.C) return;
-    float w[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8];
-    load_w8(p, c0, w, cb);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f;
-        if (p.group) {
-            mean_rstd(p, b, c0 + j, mu[j], rs[j]);
-            gm[j] = p.gamma[c0 + j];
-            bt[j] = p.beta[c0 + j];
-        }
+    const int b = blockIdx.y, c0 = threadIdx.x * 2;
+    const bool active = c0 < p.C;
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
+    T* Y = reinterpret_cast<T*>(p.y) + (long long)b * p.T0 * p.C + c0;
+    C0Thread<K> th;
+    C0Norm nm;
+    if (active) {
+        th.load(p, c0);
+        if (p.group) nm.load(p, b, c0);
     }
-    for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
-        const float* x = sx + tt * p.stride;
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float u = cb[j];
-#pragma unroll
-            for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
-            if (p.group) u = act_fwd((u - mu[j]) * rs[j] * gm[j] + bt[j], SMX_ACT_GELU);
-            o[j] = u;
+    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
+        const int t0 = tile * C0_TT;
+        __syncthreads();
+        stage_wave(p, sx, b, t0);
+        __syncthreads();
+        if (active) {
+            const int ntt = min(C0_TT, p.T0 - t0);
+#pragma unroll 2
+            for (int tt = 0; tt < ntt; ++tt) {
+                smx_f2 u = th.conv(sx + tt * p.stride);
+                if (p.group) u = gelu2(__builtin_elementwise_fma(u, nm.a, nm.b0));
+                store_pair(Y + (long long)(t0 + tt) * p.C, u);
+            }
         }
-        store8(Y + (long long)(t0 + tt) * p.C + c0, o);
     }
 }
 
 // backward pass 1 (group): S1 = sum_t dz, S2 = sum_t dz * xhat  with dz = dy * gelu'(z)
-template <typename T>
+template <typename T, int K>
 __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
-    __shared__ float red[4][64][16];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c0 = lane * 8;
+    const int b = blockIdx.y, c0 = threadIdx.x * 2;
+    const bool active = c0 < p.C;
     const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
     const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
-    const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C;
-    float s1[8], s2[8], w[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    if (c0 < p.C) {
-        load_w8(p, c0, w, cb);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            mean_rstd(p, b, c0 + j, mu[j], rs[j]);
-            gm[j] = p.gamma[c0 + j];
-            bt[j] = p.beta[c0 + j];
-        }
+    const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C + c0;
+    C0Thread<K> th;
+    C0Norm nm;
+    if (active) {
+        th.load(p, c0);
+        nm.load(p, b, c0);
     }
+    smx_f2 s1 = SMX_PK(0.f), s2 = SMX_PK(0.f);
     for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
         const int t0 = tile * C0_TT;
         __syncthreads();
         stage_wave(p, sx, b, t0);
         __syncthreads();
-        if (c0 < p.C) {
-            for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
-                const float* x = sx + tt * p.stride;
-                float d[8];
-                load8(dY + (long long)(t0 + tt) * p.C + c0, d);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float u = cb[j];
-#pragma unroll
-                    for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
-                    const float xh = (u - mu[j]) * rs[j];
-                    const float dz = d[j] * act_grad(xh * gm[j] + bt[j], SMX_ACT_GELU);
-                    s1[j] += dz;
-                    s2[j] += dz * xh;
-                }
+        if (active) {
+            const int ntt = min(C0_TT, p.T0 - t0);
+            smx_f2 a1 = SMX_PK(0.f), a2 = SMX_PK(0.f);
+#pragma unroll 2
+            for (int tt = 0; tt < ntt; ++tt) {
+                const smx_f2 d = load_pair(dY + (long long)(t0 + tt) * p.C);
+                const smx_f2 u = th.conv(sx + tt * p.stride);
+                const smx_f2 dz = d * gelu_grad2(__builtin_elementwise_fma(u, nm.a, nm.b0));
+                const smx_f2 xh = __builtin_elementwise_fma(u, nm.rs, nm.xo);
+                a1 += dz;
+                a2 = __builtin_elementwise_fma(dz, xh, a2);
             }
+            s1 += a1;
+            s2 += a2;
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { red[wv][lane][j] = s1[j]; red[wv][lane][8 + j] = s2[j]; }
-    __syncthreads();
-    if (wv == 0 && c0 < p.C) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
-            const float c = red[0][lane][8 + j] + red[1][lane][8 + j] + red[2][lane][8 + j] + red[3][lane][8 + j];
-            atomicAdd(p.bstats + ((long long)b * p.C + c0 + j) * 2, (double)a);
-            atomicAdd(p.bstats + ((long long)b * p.C + c0 + j) * 2 + 1, (double)c);
-        }
-    }
+    if (active)
+        *reinterpret_cast<float4*>(p.partials + (((long long)b * p.nb + blockIdx.x) * p.C + c0) * 2) = make_float4(s1[0], s2[0], s1[1], s2[1]);
 }
 
 // dgamma / dbeta from the per-clip sums
@@ -211,40 +231,33 @@ __global__ void conv0_bwd_affine_kernel(SmxConv0Params p) {
         a += p.bstats[((long long)b * p.C + c) * 2];
         g += p.bstats[((long long)b * p.C + c) * 2 + 1];
     }
-    if (p.dbeta) atomicAdd(p.dbeta + c, (float)a);
-    if (p.dgamma) atomicAdd(p.dgamma + c, (float)g);
+    if (p.dbeta) p.dbeta[c] += (float)a;
+    if (p.dgamma) p.dgamma[c] += (float)g;
 }
 
-// backward pass 2: du (through GroupNorm) then dW[c][t] += sum du * x[stride*t' + t].  Register accumulators
-// across `tiles_per_block` tiles, LDS reduction over the 4 waves, one fp32 atomic per (channel, tap) per block.
-template <typename T>
+// backward pass 2: du (through GroupNorm) then dW[c][t] += sum du * x[stride*t' + t].  The block's sums stay in
+// registers over all its time steps and leave as one partial row [C*k | C]; smx_colsum adds the rows into dw / dcbias.
+template <typename T, int K>
 __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
-    __shared__ float red[4][64][8];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c0 = lane * 8;
+    const int b = blockIdx.y, c0 = threadIdx.x * 2;
+    const bool active = c0 < p.C;
     const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
     const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
-    const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C;
-    const float invT = 1.0f / (float)p.T0;
-    float w[8][C0_MAXK], acc[8][C0_MAXK], cb[8], mu[8], rs[8], gm[8], bt[8], m1[8], m2[8], accb[8];
+    const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C + c0;
+    C0Thread<K> th;
+    C0Norm nm;
+    smx_f2 m1 = SMX_PK(0.f), m2 = SMX_PK(0.f), accb = SMX_PK(0.f), acc[K];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        mu[j] = 0.f; rs[j] = 1.f; gm[j] = 1.f; bt[j] = 0.f; m1[j] = m2[j] = 0.f; accb[j] = 0.f; cb[j] = 0.f;
+    for (int t = 0; t < K; ++t) acc[t] = SMX_PK(0.f);
+    if (active && p.group) {
+        th.load(p, c0);
+        nm.load(p, b, c0);
+        const float invT = 1.0f / (float)p.T0;
 #pragma unroll
-        for (int t = 0; t < C0_MAXK; ++t) { acc[j][t] = 0.f; w[j][t] = 0.f; }
-    }
-    if (c0 < p.C) {
-        load_w8(p, c0, w, cb);
-        if (p.group) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                mean_rstd(p, b, c0 + j, mu[j], rs[j]);
-                gm[j] = p.gamma[c0 + j]; bt[j] = p.beta[c0 + j];
-                m1[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2] * invT);
-                m2[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2 + 1] * invT);
-            }
+        for (int j = 0; j < 2; ++j) {
+            m1[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2] * invT);
+            m2[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2 + 1] * invT);
         }
     }
     for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
@@ -252,45 +265,33 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
         __syncthreads();
         stage_wave(p, sx, b, t0);
         __syncthreads();
-        if (c0 < p.C) {
-            for (int tt = wv; tt < C0_TT && t0 + tt < p.T0; tt += 4) {
+        if (active) {
+            const int ntt = min(C0_TT, p.T0 - t0);
+#pragma unroll 2
+            for (int tt = 0; tt < ntt; ++tt) {
                 const float* x = sx + tt * p.stride;
-                float d[8];
-                load8(dY + (long long)(t0 + tt) * p.C + c0, d);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float du = d[j];
-                    if (p.group) {
-                        float u = cb[j];
-#pragma unroll
-                        for (int t = 0; t < C0_MAXK; ++t) u = fmaf(w[j][t], x[t], u);
-                        const float xh = (u - mu[j]) * rs[j];
-                        const float dz = du * act_grad(xh * gm[j] + bt[j], SMX_ACT_GELU);
-                        du = gm[j] * rs[j] * (dz - m1[j] - xh * m2[j]);
-                    }
-                    accb[j] += du;
-#pragma unroll
-                    for (int t = 0; t < C0_MAXK; ++t) acc[j][t] = fmaf(du, x[t], acc[j][t]);
+                smx_f2 du = load_pair(dY + (long long)(t0 + tt) * p.C);
+                if (p.group) {
+                    const smx_f2 u = th.conv(x);
+                    const smx_f2 dz = du * gelu_grad2(__builtin_elementwise_fma(u, nm.a, nm.b0));
+                    const smx_f2 xh = __builtin_elementwise_fma(u, nm.rs, nm.xo);
+                    du = nm.a * (dz - m1 - xh * m2);
                 }
+                accb += du;
+#pragma unroll
+                for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(du, SMX_PK(x[t]), acc[t]);
             }
         }
     }
-    // reduce the 4 waves (same channels, different time steps), one tap at a time
+    if (active) {
+        float* row = p.partials + ((long long)b * p.nb + blockIdx.x) * ((long long)p.C * (p.k + 1));
 #pragma unroll
-    for (int t = 0; t <= C0_MAXK; ++t) {
-        if (t < C0_MAXK && t >= p.k) continue;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[wv][lane][j] = t < C0_MAXK ? acc[j][t] : accb[j];
-        __syncthreads();
-        if (wv == 0 && c0 < p.C) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j];
-                if (t < C0_MAXK) atomicAdd(p.dw + (c0 + j) * p.k + t, v);
-                else if (p.dcbias && !p.group) atomicAdd(p.dcbias + c0 + j, v);
+        for (int t = 0; t < K; ++t)
+            if (t < p.k) {
+                row[c0 * p.k + t] = acc[t][0];
+                row[(c0 + 1) * p.k + t] = acc[t][1];
             }
-        }
+        store_pair(row + (long long)p.C * p.k + c0, accb);
     }
 }
 
@@ -299,24 +300,44 @@ static int conv0_check(const SmxConv0Params& p) {
     if (p.T0 != (p.N - p.k) / p.stride + 1 || p.T0 <= 0) return SMX_EINVAL;
     return SMX_OK;
 }
+static void conv0_reduction_geometry(SmxConv0Params& p) {
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    int nb = 1024 / p.B;                       // ~1024 blocks in flight (4 per CU)
+    if (nb < 1) nb = 1;
+    if (nb > C0_NBMAX) nb = C0_NBMAX;
+    if (nb > ntiles) nb = ntiles;
+    p.tiles_per_block = (ntiles + nb - 1) / nb;
+    p.nb = (ntiles + p.tiles_per_block - 1) / p.tiles_per_block;
+}
+#define C0_LAUNCH_K(KERNEL, GRID, P, STREAM)                                                       \
+    do {                                                                                           \
+        if ((P).k == 10) hipLaunchKernelGGL((KERNEL<10>), GRID, dim3(256), 0, STREAM, P);          \
+        else hipLaunchKernelGGL((KERNEL<C0_MAXK>), GRID, dim3(256), 0, STREAM, P);                 \
+    } while (0)
+#define C0_LAUNCH_TK(KERNEL, T, GRID, P, STREAM)                                                   \
+    do {                                                                                           \
+        if ((P).k == 10) hipLaunchKernelGGL((KERNEL<T, 10>), GRID, dim3(256), 0, STREAM, P);       \
+        else hipLaunchKernelGGL((KERNEL<T, C0_MAXK>), GRID, dim3(256), 0, STREAM, P);              \
+    } while (0)
 
 extern "C" int smx_conv0_fwd(const SmxConv0Params* pp, int dtype, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxConv0Params p = *pp;
     int rc = conv0_check(p);
     if (rc) return rc;
+    if (dtype != SMX_F32 && dtype != SMX_BF16) return SMX_EINVAL;
     const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
-    dim3 grid(ntiles, p.B);
-    p.tiles_per_block = max(1, (ntiles * p.B + 1023) / 1024);
-    dim3 rgrid((ntiles + p.tiles_per_block - 1) / p.tiles_per_block, p.B);
     if (p.group) {
-        if (!p.stats || !p.gamma || !p.beta) return SMX_EINVAL;
-        hipMemsetAsync(p.stats, 0, sizeof(double) * 2 * p.B * p.C, stream);
-        hipLaunchKernelGGL(conv0_stats_kernel, rgrid, dim3(256), 0, stream, p);
+        if (!p.stats || !p.gamma || !p.beta || !p.partials) return SMX_EINVAL;
+        conv0_reduction_geometry(p);
+        C0_LAUNCH_K(conv0_stats_kernel, dim3(p.nb, p.B), p, stream);
+        const int n = p.B * p.C * 2;
+        hipLaunchKernelGGL(conv0_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p.partials, p.stats, p.B, p.C, p.nb);
     }
-    if (dtype == SMX_F32) hipLaunchKernelGGL(conv0_apply_kernel<float>, grid, dim3(256), 0, stream, p);
-    else if (dtype == SMX_BF16) hipLaunchKernelGGL(conv0_apply_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
-    else return SMX_EINVAL;
+    p.tiles_per_block = 4;
+    const dim3 grid((ntiles + 3) / 4, p.B);
+    if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_apply_kernel, float, grid, p, stream);
+    else C0_LAUNCH_TK(conv0_apply_kernel, bf16_t, grid, p, stream);
     SMX_CHECK_LAUNCH();
 }
 
@@ -327,19 +348,29 @@ extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t st
     int rc = conv0_check(p);
     if (rc) return rc;
     if (dtype != SMX_F32 && dtype != SMX_BF16) return SMX_EINVAL;
-    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
-    p.tiles_per_block = max(1, (ntiles * p.B + 1023) / 1024);
-    dim3 grid((ntiles + p.tiles_per_block - 1) / p.tiles_per_block, p.B);
+    if (!p.partials) return SMX_EINVAL;
+    conv0_reduction_geometry(p);
+    const dim3 grid(p.nb, p.B);
     if (p.group) {
         if (!p.stats || !p.bstats) return SMX_EINVAL;
-        hipMemsetAsync(p.bstats, 0, sizeof(double) * 2 * p.B * p.C, stream);
-        if (dtype == SMX_F32) hipLaunchKernelGGL(conv0_bwd_stats_kernel<float>, grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL(conv0_bwd_stats_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+        if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_stats_kernel, float, grid, p, stream);
+        else C0_LAUNCH_TK(conv0_bwd_stats_kernel, bf16_t, grid, p, stream);
+        const int n = p.B * p.C * 2;
+        hipLaunchKernelGGL(conv0_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p.partials, p.bstats, p.B, p.C, p.nb);
         hipLaunchKernelGGL(conv0_bwd_affine_kernel, dim3((p.C + 255) / 256), dim3(256), 0, stream, p);
     }
     if (p.dw) {
-        if (dtype == SMX_F32) hipLaunchKernelGGL(conv0_bwd_w_kernel<float>, grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL(conv0_bwd_w_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+        if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_w_kernel, float, grid, p, stream);
+        else C0_LAUNCH_TK(conv0_bwd_w_kernel, bf16_t, grid, p, stream);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        const long long ld = (long long)p.C * (p.k + 1);
+        rc = smx_colsum(p.partials, p.dw, p.B * p.nb, p.C * p.k, ld, 1.0f, SMX_F32, stream);
+        if (rc) return rc;
+        if (p.dcbias && !p.group) {
+            rc = smx_colsum(p.partials + (long long)p.C * p.k, p.dcbias, p.B * p.nb, p.C, ld, 1.0f, SMX_F32, stream);
+            if (rc) return rc;
+        }
     }
     SMX_CHECK_LAUNCH();
 }

@@ -410,18 +410,19 @@ class Engine:
         C0, T0 = ec.conv_dim[0], Ts[0]
         cb0 = self.P(p0 + "conv.bias") if ec.conv_bias else None
         y0 = self.new(B * T0, C0)
+        c0ws = self.workspace("conv0_partials", ops.conv0_workspace_floats(B, C0, ec.conv_kernel[0]), torch.float32)
         if group:
             stats = self.new(B * C0 * 2, dt=torch.float64)
             c0 = ops.conv0_params(wave, self.P(p0 + "conv.weight"), cb0, self.P(p0 + "layer_norm.weight"),
                                   self.P(p0 + "layer_norm.bias"), stats, y0, B, N, C0, ec.conv_kernel[0],
-                                  ec.conv_stride[0], T0, True)
+                                  ec.conv_stride[0], T0, True, partials=c0ws)
             ops.conv0_fwd(c0, self.dt)
             sv["c0"], sv["stats"] = c0, stats
             sv["ln"].append(None)
         else:
             u0 = y0
             c0 = ops.conv0_params(wave, self.P(p0 + "conv.weight"), cb0, None, None, None, u0, B, N, C0,
-                                  ec.conv_kernel[0], ec.conv_stride[0], T0, False)
+                                  ec.conv_kernel[0], ec.conv_stride[0], T0, False, partials=c0ws)
             ops.conv0_fwd(c0, self.dt)
             sv["c0"] = c0
             y0, lnsv = self.ln_fwd(u0, p0 + "layer_norm.weight", p0 + "layer_norm.bias", B * T0, C0, 1e-5, act=ACT_GELU)

@@ -187,8 +187,15 @@ def attention_bwd(desc, lse, delta, dtype, dbias=None):
     L.check(L.lib().smx_attention_bwd(C.byref(desc.p), dtype, _stream()), "smx_attention_bwd")
 
 
-def conv0_params(wave, w, cbias, gamma, beta, stats, y, B, N, Cc, k, stride, T0, group, eps=1e-5):
+def conv0_workspace_floats(B, Cc, k):
+    fn = L.lib().smx_conv0_workspace_floats
+    fn.restype = C.c_longlong
+    return int(fn(B, Cc, k))
+
+
+def conv0_params(wave, w, cbias, gamma, beta, stats, y, B, N, Cc, k, stride, T0, group, eps=1e-5, partials=None):
     p = L.Conv0Params()
+    p.partials = _ptr(partials)
     p.wave, p.w, p.cbias, p.gamma, p.beta, p.stats, p.y = _ptr(wave), _ptr(w), _ptr(cbias), _ptr(gamma), _ptr(beta), \
         _ptr(stats), _ptr(y)
     p.B, p.N, p.C, p.k, p.stride, p.T0, p.group, p.eps = B, N, Cc, k, stride, T0, int(group), eps

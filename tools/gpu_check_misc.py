@@ -32,7 +32,9 @@ def conv0_case(dtype, tdt, tol, group, B=2, N=4000, C=32, k=10, s=5, bias=False)
     waved = wave.to(dev)
     yd = torch.zeros(B * T0, C, dtype=tdt, device=dev)
     stats = torch.zeros(B * C * 2, dtype=torch.float64, device=dev)
-    p = ops.conv0_params(waved, wd, cbd, gd if group else None, bd if group else None, stats if group else None, yd, B, N, C, k, s, T0, group)
+    ws = torch.empty(ops.conv0_workspace_floats(B, C, k), dtype=torch.float32, device=dev)
+    p = ops.conv0_params(waved, wd, cbd, gd if group else None, bd if group else None, stats if group else None, yd, B, N, C, k, s, T0, group,
+                         partials=ws)
     ops.conv0_fwd(p, dtype)
     nm = f"conv0 dt{dtype} group{int(group)} bias{int(bias)}"
     ok &= check(nm + " fwd", yd.view(B, T0, C), yr.detach(), tol)
