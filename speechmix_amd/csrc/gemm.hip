@@ -499,11 +499,24 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) 
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const int nwg = ntn * ntm;
+    // Split-K launches (weight gradients: few output tiles, very long K) are bound by the operand fills.  All tiles of
+    // one K slice read the same rows of A and B, so they should share an L2.  Workgroups go to XCDs round-robin in
+    // dispatch order (dispatch id L -> XCD L % 8): give XCD c a CONTIGUOUS range of the slice-major work list
+    // (slice, tile), i.e. whole slices or contiguous tile runs of at most two slices.
+    const bool xcd_split = p.split_k > 1 && p.nbatch == 1 && (int)gridDim.x == nwg;
+    int lin0 = blockIdx.x, z = blockIdx.z;
+    if (xcd_split) {
+        const int W = nwg * p.split_k, L = blockIdx.x + nwg * blockIdx.z;
+        const int c = L & 7, j = L >> 3, base = W >> 3, rem = W & 7;
+        const int w = c * base + min(c, rem) + j;
+        z = w / nwg;
+        lin0 = w - z * nwg;
+    }
     // persistent over tiles when launched with fewer blocks than tiles: blocks then walk the tile list in step,
     // so the workgroups sharing an L2 read the same K slices of their shared panels at about the same time
-    for (int lin = blockIdx.x; lin < nwg; lin += gridDim.x) {
+    for (int lin = lin0; lin < nwg; lin += gridDim.x) {
     int wg = lin;
-    {
+    if (!xcd_split) {
         const int q = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
@@ -520,7 +533,6 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) 
         tn = first + (rem - tm * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.z;
     const int zb = z / p.split_k, zs = z - zb * p.split_k;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;

@@ -101,7 +101,7 @@ class Engine:
         ksteps = (Kred + 63) // 64
         # 4 workgroups/CU x 256 CUs are resident at once: aim for ~1 full wave of workgroups, keep every split
         # non-empty and at least 8 K-steps long (slab traffic grows with the split count)
-        want = int(max(1, min((1024 + tiles - 1) // max(tiles, 1), ksteps // 8, 32)))
+        want = int(max(1, min(1024 // max(tiles, 1), ksteps // 8, 32)))       # floor: one resident wave, no tail round
         per = (ksteps + want - 1) // want
         return (ksteps + per - 1) // per
 

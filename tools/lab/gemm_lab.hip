@@ -6,7 +6,7 @@
 #include <vector>
 
 // MODE 0: full loop, no epilogue   1: loads only   2: LDS reads + MFMA only (no global loads)
-template <int MODE>
+template <int MODE, bool A_RC = false, bool B_RC = false>
 __global__ __launch_bounds__(256, 4) void lab_kernel(SmxGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -32,10 +32,13 @@ __global__ __launch_bounds__(256, 4) void lab_kernel(SmxGemmParams p) {
         const int m0 = tm * BM, n0 = tn * BN;
         const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
         const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-        const int ks1 = (p.K + BK - 1) / BK;
-        DmaLoader<false> la, lb;
-        la.init(A, p.a, m0, p.M, 0, tid);
-        lb.init(B, p.b, n0, p.N, 0, tid);
+        const int kst = (p.K + BK - 1) / BK;
+        const int per = (kst + p.split_k - 1) / p.split_k;
+        const int ksb = blockIdx.z * per, ks1 = min(kst, ksb + per);
+        DmaLoader<A_RC> la;
+        DmaLoader<B_RC> lb;
+        la.init(A, p.a, m0, p.M, ksb * BK, tid);
+        lb.init(B, p.b, n0, p.N, ksb * BK, tid);
         f32x4_t acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256, 4) void lab_kernel(SmxGemmParams p) {
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         char* tA = smem;
         char* tB = smem + 16384;
-        for (int ks = 0; ks < ks1; ++ks) {
+        for (int ks = ksb; ks < ks1; ++ks) {
             if (MODE != 2) {
                 la.issue(tA, p.a, m0, p.M, ks * BK, p.K, tid);
                 lb.issue(tB, p.b, n0, p.N, ks * BK, p.K, tid);
@@ -54,9 +57,9 @@ __global__ __launch_bounds__(256, 4) void lab_kernel(SmxGemmParams p) {
                 for (int kk = 0; kk < 2; ++kk) {
                     bf16x8_t fa[4], fb[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[i] = load_frag<false>(tA, wm * 64 + i * 16, kk, lane, 1);
+                    for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_RC>(tA, wm * 64 + i * 16, kk, lane, 1);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[j] = load_frag<false>(tB, wn * 64 + j * 16, kk, lane, 1);
+                    for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_RC>(tB, wn * 64 + j * 16, kk, lane, 1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -132,6 +135,33 @@ int main(int argc, char** argv) {
             }
             printf("\n");
         }
+        CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    }
+    // weight-gradient shapes: C[M,N] = A^T B with both operands rows-contiguous ([K, M] and [K, N]), split-K slabs
+    const int wshapes[][4] = {{768, 3072, 15968, 7}, {768, 3072, 15968, 6}, {2304, 768, 15968, 9}, {2304, 768, 15968, 8}, {512, 1536, 511968, 21}, {512, 1536, 511968, 16}, {512, 1536, 511968, 12}, {768, 768, 15968, 28}, {768, 768, 15968, 21}, {768, 768, 15968, 14}, {50265, 768, 1024, 1}};
+    for (auto& s : wshapes) {
+        const int M = s[0], N = s[1], K = s[2], split = s[3];
+        bf16_t *A, *B; float* C;
+        CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4 * split));
+        CK(hipMemset(A, 0x3c, (size_t)M * K * 2)); CK(hipMemset(B, 0x3c, (size_t)N * K * 2));
+        const double fl = 2.0 * M * N * K;
+        const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        SmxGemmParams p = {};
+        p.A = A; p.B = B; p.C = C;
+        p.a = SmxRowView{0, M, 0, 0, 0}; p.b = SmxRowView{0, N, 0, 0, 0}; p.c = SmxRowView{0, N, 0, 0, 0}; p.e = p.c;
+        p.M = M; p.N = N; p.K = K; p.nbatch = 1; p.split_k = split; p.alpha = 1.f; p.a_rc = 1; p.b_rc = 1; p.out_f32 = 1;
+        p.split_stride = (long long)M * N; p.tr_mode = 1;
+        dim3 grid(tiles > 1024 ? 1024 : tiles, 1, split);
+        float t_full = time_us([&] { smx_gemm(&p, SMX_BF16, 0); });
+        float t0 = time_us([&] { hipLaunchKernelGGL((lab_kernel<0, true, true>), grid, dim3(256), 32768, 0, p); });
+        float t1 = time_us([&] { hipLaunchKernelGGL((lab_kernel<1, true, true>), grid, dim3(256), 32768, 0, p); });
+        float t2 = time_us([&] { hipLaunchKernelGGL((lab_kernel<2, true, true>), grid, dim3(256), 32768, 0, p); });
+        p.split_k = 1; p.a_rc = 0; p.b_rc = 0; p.a = SmxRowView{0, K, 0, 0, 0}; p.b = SmxRowView{0, K, 0, 0, 0};
+        p.split_k = split;
+        float t3 = time_us([&] { hipLaunchKernelGGL((lab_kernel<0, false, false>), grid, dim3(256), 32768, 0, p); });
+        printf("wgrad M=%d N=%d K=%d split=%d tiles=%d: production %.1f us (%.0f TF) | no-epilogue %.1f us (%.0f TF) | loads-only %.1f us | "
+               "compute-only %.1f us (%.0f TF) | same shape with K-contiguous operands, no epilogue %.1f us (%.0f TF)\n", M, N, K, split, tiles,
+               t_full, fl / t_full / 1e6, t0, fl / t0 / 1e6, t1, t2, fl / t2 / 1e6, t3, fl / t3 / 1e6);
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
     }
     return 0;
