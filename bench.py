@@ -153,10 +153,19 @@ def main():
             summ = prof.summary()
             dom = max(summ, key=lambda k: summ[k]["total_ms"])
             d = summ[dom]
-            line["roofline"] = {"kernel": ops.GemmProfile.NAMES[dom], "bound": "mfma", "achieved": round(d["tflops"], 1),
+            kname = ops.GemmProfile.NAMES[dom]
+            line["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(d["tflops"], 1),
                                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                                "avg_launch_us": round(d["avg_us"], 2), "launches": d["launches"]}
+                                "avg_launch_us": round(d["avg_us"], 2), "launches": d["launches"],
+                                "flops_per_launch": round(d["flops"] / d["launches"])}
+            # HBM-side bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+            if os.path.exists(pmc):
+                k = json.load(open(pmc))["kernels"].get(kname.split(" ")[0])
+                if k:
+                    line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             line["gemm_variants"] = {ops.GemmProfile.NAMES[k]: {"tflops": round(v["tflops"], 1),
                                                                   "ms_per_step": round(v["total_ms"] / args.steps, 3),
                                                                   "launches_per_step": v["launches"] // args.steps}
