@@ -49,14 +49,16 @@ def stage_ranges(offsets: Dict[str, Tuple[int, int, tuple]], num_speech_layers: 
 
 
 class GradReducer:
-    def __init__(self, flat_grad: torch.Tensor, stages, group=None):
+    def __init__(self, flat_grad: torch.Tensor, stages, group=None, force_comm: bool = False):
+        """force_comm: issue the collectives even in a 1-rank group (exercises the RCCL / side-stream path on one GPU)."""
         self.g = flat_grad
         self.stages = dict(stages)
         self.order = [s for s, _ in stages]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_comm and dist.is_initialized())
         self.cuda = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.cuda and self.world > 1 else None
+        self.comm_stream = torch.cuda.Stream() if self.cuda and self.active else None
         self._done = set()
         covered = sorted(r for rs in self.stages.values() for r in rs)
         for (a0, b0), (a1, b1) in zip(covered[:-1], covered[1:]):
@@ -68,7 +70,7 @@ class GradReducer:
 
     def stage_done(self, name: str):
         """Called by the engine on the compute stream right after the stage's last gradient kernel."""
-        if self.world == 1 or name in self._done or name not in self.stages:
+        if not self.active or name in self._done or name not in self.stages:
             self._done.add(name)
             return
         self._done.add(name)

@@ -34,7 +34,7 @@ def trainable_ranges(store) -> List[Tuple[int, int]]:
 
 class StepRunner:
     def __init__(self, model, lr=4e-5, optimizer="adamw", betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_grad_norm=1.0, momentum=0.0):
+                 max_grad_norm=1.0, momentum=0.0, force_comm=False):
         model._need_engine()
         self.model, self.store, self.engine = model, model.store, model.engine
         self.kind = optimizer
@@ -48,7 +48,8 @@ class StepRunner:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
         self.ranges = trainable_ranges(self.store)
-        self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, model.num_speech_encoder_layers))
+        self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, model.num_speech_encoder_layers),
+                                   force_comm=force_comm)
         self.engine.stage_cb = self.reducer.stage_done
         self.store.external_updates = False          # this runner keeps the bf16 compute copies fresh itself
         self.store.refresh_shadow(force=True)

@@ -77,6 +77,77 @@ __global__ __launch_bounds__(256, 4) void lab_kernel(SmxGemmParams p) {
     if (sink == 1234.5678f) reinterpret_cast<float*>(p.C)[tid] = sink;
 }
 
+// 256 x 128 x 64 tile, 4 waves of 128 x 64 (acc 8x4), one 48-KB LDS buffer, 3 workgroups / CU.  MODE as above.
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void lab256_kernel(SmxGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + 127) / 128, ntm = (p.M + 255) / 256;
+    const int nwg = ntn * ntm;
+    float sink = 0.f;
+    for (int lin = blockIdx.x; lin < nwg; lin += gridDim.x) {
+        int wg = lin;
+        {
+            const int q = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
+            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        }
+        int tm, tn;
+        {
+            const int per_group = GROUP_N * ntm;
+            const int grp = wg / per_group, rem = wg - grp * per_group;
+            const int first = grp * GROUP_N;
+            const int gsz = min(ntn - first, GROUP_N);
+            tm = rem / gsz;
+            tn = first + (rem - tm * gsz);
+        }
+        const int m0 = tm * 256, n0 = tn * 128;
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+        const int ks1 = (p.K + BK - 1) / BK;
+        DmaLoader<false> la0, la1, lb;
+        la0.init(A, p.a, m0, p.M, 0, tid);
+        la1.init(A, p.a, m0 + 128, p.M, 0, tid);
+        lb.init(B, p.b, n0, p.N, 0, tid);
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        char* tA = smem;
+        char* tB = smem + 32768;
+        for (int ks = 0; ks < ks1; ++ks) {
+            if (MODE != 2) {
+                la0.issue(tA, p.a, m0, p.M, ks * BK, p.K, tid);
+                la1.issue(tA + 16384, p.a, m0 + 128, p.M, ks * BK, p.K, tid);
+                lb.issue(tB, p.b, n0, p.N, ks * BK, p.K, tid);
+            }
+            __syncthreads();
+            if (MODE != 1) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8_t fa[8], fb[4];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) fa[i] = load_frag<false>(tA + wm * 16384, i * 16, kk, lane, 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[j] = load_frag<false>(tB, wn * 64 + j * 16, kk, lane, 1);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sink += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    }
+    if (sink == 1234.5678f) reinterpret_cast<float*>(p.C)[tid] = sink;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -97,7 +168,7 @@ static float time_us(F&& f, int n = 20) {
 int main(int argc, char** argv) {
     const bool stripped = argc > 1 && atoi(argv[1]) == 1;
     const int shapes[][3] = {{15968, 3072, 768}, {15968, 768, 3072}, {15968, 768, 768}, {16384, 4096, 1024}, {1024, 768, 768},
-                             {1024, 768, 3072}, {1024, 3072, 768}, {7968, 768, 768}};
+                             {1024, 768, 3072}, {1024, 3072, 768}, {7968, 768, 768}, {511968, 512, 1536}, {15968, 2304, 768}};
     for (auto& s : shapes) {
         const int M = s[0], N = s[1], K = s[2];
         bf16_t *A, *B, *C;
@@ -116,6 +187,18 @@ int main(int argc, char** argv) {
             float t0 = time_us([&] { hipLaunchKernelGGL(lab_kernel<0>, grid, dim3(256), 32768, 0, p); });
             float t1 = time_us([&] { hipLaunchKernelGGL(lab_kernel<1>, grid, dim3(256), 32768, 0, p); });
             float t2 = time_us([&] { hipLaunchKernelGGL(lab_kernel<2>, grid, dim3(256), 32768, 0, p); });
+            {
+                int t256 = ((M + 255) / 256) * ((N + 127) / 128);
+                dim3 g2(t256 > 768 ? 768 : t256);
+                (void)hipFuncSetAttribute((const void*)lab256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+                (void)hipFuncSetAttribute((const void*)lab256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+                (void)hipFuncSetAttribute((const void*)lab256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152);
+                float u0 = time_us([&] { hipLaunchKernelGGL(lab256_kernel<0>, g2, dim3(256), 49152, 0, p); });
+                float u1 = time_us([&] { hipLaunchKernelGGL(lab256_kernel<1>, g2, dim3(256), 49152, 0, p); });
+                float u2 = time_us([&] { hipLaunchKernelGGL(lab256_kernel<2>, g2, dim3(256), 49152, 0, p); });
+                printf("   256x128 tile (%d tiles): no-epilogue %.1f us (%.0f TF) | loads-only %.1f us | compute-only %.1f us (%.0f TF)\n", t256, u0,
+                       fl / u0 / 1e6, u1, u2, fl / u2 / 1e6);
+            }
             const double bytes = (double)tiles * ((K + 63) / 64) * 32768.0;
             printf("M=%d N=%d K=%d tiles=%d: production %.1f us (%.0f TF) | no-epilogue %.1f us (%.0f TF) | loads-only %.1f us (%.2f TB/s L2->LDS) | "
                    "compute-only %.1f us (%.0f TF)\n", M, N, K, tiles, t_full, fl / t_full / 1e6, t0, fl / t0 / 1e6, t1, bytes / t1 / 1e6, t2, fl / t2 / 1e6);
