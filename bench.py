@@ -175,7 +175,7 @@ def main():
             summ = prof.summary()
             dom = max(summ, key=lambda k: summ[k]["total_ms"])
             d = summ[dom]
-            kname = ops.GemmProfile.NAMES[dom]
+            kname = ops.GemmProfile.name(dom)
             line["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(d["tflops"], 1),
                                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
@@ -189,7 +189,7 @@ def main():
                 if k:
                     line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-            line["gemm_variants"] = {ops.GemmProfile.NAMES[k]: {"tflops": round(v["tflops"], 1),
+            line["gemm_variants"] = {ops.GemmProfile.name(k): {"tflops": round(v["tflops"], 1),
                                                                   "ms_per_step": round(v["total_ms"] / args.steps, 3),
                                                                   "launches_per_step": v["launches"] // args.steps}
                                      for k, v in summ.items()}

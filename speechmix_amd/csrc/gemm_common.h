@@ -1,0 +1,253 @@
+// Shared pieces of the bf16 GEMM kernels (gemm.hip: 128x128 family; gemm_pp.hip: 256-wide ping-pong kernel):
+// the parameter block of the C ABI, the LDS tile images, fragment reads, LDS-DMA helpers and the row epilogue.
+#pragma once
+#include "smx_common.h"
+
+struct SmxGemmParams {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;      // [N] fp32 or null
+    const void* resid;      // same view as C (dtype = in dtype) or null: C += resid
+    void* aux_out;          // pre-activation copy (same view as C) or null
+    const void* aux_in;     // pre-activation of the consumer: C *= act'(aux_in) (same view as C) or null
+    SmxRowView a, b, c;
+    SmxRowView e;           // view of the epilogue side tensors (resid / aux_out / aux_in); usually == c
+    long long batch_a, batch_b, batch_c, batch_bias, batch_e;  // element strides between grid.z batches
+    int M, N, K;
+    int a_rc, b_rc;
+    int act;                // SMX_ACT_* applied after bias (fwd) or used for aux_in derivative
+    int out_f32;            // C is fp32 regardless of input dtype
+    int atomic;             // 0: C = .., 1: C += via fp32 atomics, 2: C += by plain read-modify-write (split_k == 1)
+    int nbatch, split_k;    // split_k > 1 with atomic == 0: split s writes its partial to C + s * split_stride ("slabs")
+    int tr_mode;            // 1: LDS-DMA kernel (production), 2: register-staged + tr reads, 0: 16-bit LDS reads (debug)
+    float alpha;
+    long long split_stride; // elements between split-K slabs (atomic == 0)
+    float drop_p;           // dropout applied after the activation and before the residual add (0: off); in the
+    unsigned drop_seed;     // aux_in (backward-through-activation) mode it multiplies by the same forward mask
+};
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GROUP_N 8
+#define KC_TILE_BYTES (128 * 128)            // 128 rows x 64 bf16
+#define RC_TILE_BYTES (64 * 256)             // 64 k-rows x 128 bf16
+#define STAGE_BYTES (2 * 16384)
+
+__device__ __forceinline__ int kc_addr(int row, int chunk) {  // chunk: 16-B unit 0..7
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ int rc_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+__device__ __forceinline__ int rc_addr(int k, int col) {      // col: element 0..127
+    return k * 256 + ((((col >> 4) ^ rc_swz(k)) << 5) | ((col & 15) << 1));
+}
+
+// gfx950 transposing LDS read: within each 16-lane group the 16 lanes x 4 b16 addressed by the lanes
+// form a [4][16] block (lanes 4q..4q+3 supply row q); lane i receives column i (4 values, k = 0..3).
+__device__ __forceinline__ uint2 lds_tr_b64(const char* p) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    union { s16x4_t v; uint2 u; } r;
+    r.v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(p));
+    return r.u;
+}
+
+template <bool RC>
+struct TileLoader {
+    // per-thread staging: 4 x 16 B
+    uint4 r[4];
+    long long off[4];   // KC: element offset of my 4 rows (chunk added); RC: unused
+    bool ok[4];
+
+    __device__ __forceinline__ void init(const SmxRowView& v, int row0, int nrows, int tid) {
+        if (!RC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = row0 + (tid >> 3) + 32 * p;
+                ok[p] = row < nrows;
+                off[p] = view_off(v, ok[p] ? row : 0) + (tid & 7) * 8;
+            }
+        }
+    }
+    // KC: rows fixed, k advances.  RC: k-rows advance (view applied per k-row), cols fixed.
+    __device__ __forceinline__ void load(const bf16_t* base, const SmxRowView& v, int row0, int nrows, int k0, int K,
+                                         int tid) {
+        if (!RC) {
+            const int kk = k0 + (tid & 7) * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (ok[p] && kk < K) r[p] = *reinterpret_cast<const uint4*>(base + off[p] + k0);
+                else r[p] = make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const int col = row0 + (tid & 15) * 8;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = k0 + (tid >> 4) + 16 * p;
+                if (k < K && col < nrows) r[p] = *reinterpret_cast<const uint4*>(base + view_off(v, k) + col);
+                else r[p] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+        if (!RC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<uint4*>(tile + kc_addr((tid >> 3) + 32 * p, tid & 7)) = r[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<uint4*>(tile + rc_addr((tid >> 4) + 16 * p, (tid & 15) * 8)) = r[p];
+        }
+    }
+};
+
+// fragment for the 16 rows starting at `r16` of the tile, K sub-step kk (0/1): 8 bf16 for k = 32kk+8g+e
+template <bool RC>
+__device__ __forceinline__ bf16x8_t load_frag(const char* tile, int r16, int kk, int lane, int tr_mode) {
+    const int i = lane & 15, g = lane >> 4;
+    union { bf16x8_t v; uint4 u; uint2 h[2]; bf16_t s[8]; } f;
+    if (!RC) {
+        f.u = *reinterpret_cast<const uint4*>(tile + kc_addr(r16 + i, kk * 4 + g));
+    } else if (tr_mode) {
+        // 16-lane group g reads a [4 k][16 col] block: lane supplies the 8-B address of (k = q, cols 4c..4c+3)
+        const int q = i >> 2, c4 = (i & 3) * 4;
+        const int kb = kk * 32 + 8 * g + q;
+        f.h[0] = lds_tr_b64(tile + rc_addr(kb, r16 + c4));
+        f.h[1] = lds_tr_b64(tile + rc_addr(kb + 4, r16 + c4));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            f.s[e] = *reinterpret_cast<const bf16_t*>(tile + rc_addr(kk * 32 + 8 * g + e, r16 + i));
+    }
+    return f.v;
+}
+
+static __device__ uint4 smx_zero_page[4];
+
+typedef __attribute__((address_space(3))) void* lds_vp_t;
+typedef const __attribute__((address_space(1))) void* glb_vp_t;
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_vp_t)src, (lds_vp_t)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void glds16_asm(const bf16_t* src, const char* lds_wave_base) {
+    typedef __attribute__((address_space(3))) const char* lds_cp_t;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(dst)
+                 : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-major epilogue for the MFMA kernels.  The accumulator layout (lane = one m, 4 consecutive n per 16x16 block)
+// gives 8-byte accesses scattered over 16 rows and one address computation per block; measured on the FFN shapes
+// that epilogue cost as much as the whole K loop.  Here each wave transposes its 64x64 fp32 sub-tile through a
+// wave-private 8-KB LDS slice (two halves of 32 rows, XOR-swizzled 16-B chunks: conflict-free both ways), after
+// which a lane owns 8 consecutive n of one row: one address per row visit, 16-B loads of resid / aux_in, 16-B
+// stores of C / aux_out (128 contiguous bytes per 8 lanes), bias held in registers for the whole tile.
+// ------------------------------------------------------------------------------------------------
+// Stores issued from inline asm are invisible to hipcc's waitcnt pass.  The persistent ping-pong kernel uses them
+// (ASM_ST) so that no compiler-tracked VMEM operation is pending when its K loop starts: with tracked stores in
+// flight hipcc drains the whole queue - its LDS-DMA prefetches included - before the first LDS read of every K tile.
+typedef __attribute__((ext_vector_type(4))) unsigned smx_u32x4_t;
+__device__ __forceinline__ void st_b128(void* p, uint4 v) {
+    const smx_u32x4_t r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ void st_b32(void* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_b16(void* p, unsigned v) {
+    asm volatile("global_store_short %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+template <bool ASM_ST>
+__device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
+    if (!ASM_ST) { store8(p, v); return; }
+    st_b128(p, make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])));
+}
+template <bool ASM_ST>
+__device__ __forceinline__ void st8(float* p, const float v[8]) {
+    if (!ASM_ST) { store8(p, v); return; }
+    st_b128(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    st_b128(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+}
+
+template <bool ASM_ST = false>
+__device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long zc, long long ze, int m, int n, float x[8],
+                                              const float bs[8], unsigned th, float inv_keep) {
+    const long long base = zc + view_off(p.c, m) + n;
+    const bool side = p.resid || p.aux_out || p.aux_in;
+    const long long sb = side ? ze + view_off(p.e, m) + n : 0;
+    const int nv = min(8, p.N - n);
+    const bool fast = nv == 8 && !(base & 7) && !(sb & 7);
+    const bf16_t* aux_in = reinterpret_cast<const bf16_t*>(p.aux_in);
+    const bf16_t* resid = reinterpret_cast<const bf16_t*>(p.resid);
+    bf16_t* aux_out = reinterpret_cast<bf16_t*>(p.aux_out);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[e]);
+    if (fast) {
+        if (aux_out) st8<ASM_ST>(aux_out + sb, x);
+        if (aux_in) {
+            float a[8];
+            load8(aux_in + sb, a);
+            act_grad_mul8(x, a, p.act);
+        } else if (p.act) {
+            act_fwd8(x, p.act);
+        }
+        if (p.drop_p > 0.f) {
+            const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
+        }
+        if (resid) {
+            float r[8];
+            load8(resid + sb, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += r[e];
+        }
+        if (!p.out_f32) {
+            st8<ASM_ST>(reinterpret_cast<bf16_t*>(p.C) + base, x);
+        } else {
+            float* c = reinterpret_cast<float*>(p.C) + base;
+            if (!ASM_ST && p.atomic == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(c + e, x[e]);
+            } else {
+                if (p.atomic == 2) {
+                    float o[8];
+                    load8(c, o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += o[e];
+                }
+                st8<ASM_ST>(c, x);
+            }
+        }
+        return;
+    }
+    // ragged / unaligned tail (LM head with V % 8 != 0, odd views): element-wise
+    for (int e = 0; e < nv; ++e) {
+        float v = x[e];
+        if (aux_out) {
+            if (ASM_ST) st_b16(aux_out + sb + e, f2bf(v)); else aux_out[sb + e] = f2bf(v);
+        }
+        if (aux_in) v *= act_grad(bf2f(aux_in[sb + e]), p.act);
+        else v = act_fwd(v, p.act);
+        if (p.drop_p > 0.f) v *= smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n + e + zc), th, inv_keep);
+        if (resid) v += bf2f(resid[sb + e]);
+        if (!p.out_f32) {
+            if (ASM_ST) st_b16(reinterpret_cast<bf16_t*>(p.C) + base + e, f2bf(v));
+            else reinterpret_cast<bf16_t*>(p.C)[base + e] = f2bf(v);
+        } else {
+            float* c = reinterpret_cast<float*>(p.C) + base + e;
+            if (!ASM_ST && p.atomic == 1) atomicAdd(c, v);
+            else {
+                if (p.atomic == 2) v += *c;
+                if (ASM_ST) st_b32(c, __float_as_uint(v)); else *c = v;
+            }
+        }
+    }
+}
+

@@ -1,0 +1,648 @@
+// ------------------------------------------------------------------------------------------------
+// bf16 "ping-pong" GEMM: 256 x 256 x 64 tile, 8 waves (2 x 4, 128 x 64 per wave), ONE persistent workgroup per CU
+// (same SmxGemmParams contract, operand views and row epilogue as the 128x128 kernels of gemm.hip).
+//
+// Why: a 128x128 tile needs 64 B/clk/CU of L2->LDS fill to keep the matrix pipes busy - the whole L2 bandwidth of the
+// chip.  256x256 halves the fill per flop, but only one such workgroup fits a CU, so nothing else hides its latencies:
+// the schedule has to.
+//
+//  * Every K tile (64 deep) is cut into four 16-KB LDS units: AH0/AH1 = first/second 64 rows of each wave-row group,
+//    BH0/BH1 = first/second 32 columns of each wave-column group.  A K tile is computed in four phases of 16 MFMAs -
+//    one quadrant of the wave's output x K=64 - in the order (AH0,BH0) (AH0,BH1) (AH1,BH1) (AH1,BH0): a phase reads at
+//    most one new A and one new B register sub-tile, and the last phase reads nothing.
+//  * The two wave-row groups run ONE barrier apart (the second group executes an extra s_barrier up front): while one
+//    group's waves issue their 16 MFMAs, the partner wave on the same SIMD does its LDS reads and issues the LDS-DMA
+//    of a later unit.  s_setprio(1) around the MFMA block.
+//  * The (work item, K tile) pairs of a workgroup form ONE flat stream of units.  Each phase issues exactly one unit,
+//    six units ahead of the one it consumes, so the fill of the next output tile's first K tiles is in flight while the
+//    current tile's epilogue runs; the only waits are counted (s_waitcnt vmcnt(8): four units may stay in flight),
+//    placed one phase before the first read of the unit they retire.  A unit is re-filled no earlier than two phases
+//    after its last read.
+//  * LDS-DMA = `buffer_load_dwordx4 ... offen lds` from inline asm (hipcc would drain a DMA it knows about before every
+//    barrier and LDS read): per-lane byte offsets are fixed per work item, the K position rides in the scalar offset,
+//    and rows / k outside the operand carry an offset beyond num_records, which the hardware fills with zeros.
+//  * No LDS in the epilogue: the B fragments are read with their columns permuted (fragment j, column 4g+r of a
+//    32-column half <-> logical column 8g + 4j + r), so a lane ends up owning 8 consecutive columns of one row per
+//    half - exactly what the shared row epilogue (16-B accesses, fused bias / activation / dropout / residual) takes.
+//    Its stores are inline asm too: any VMEM operation hipcc still tracks when the next K loop starts makes it drain
+//    the whole queue before the first LDS read of every K tile.
+//  * Work list: (K slice | batch, output tile), slice-major, handed out so that each XCD owns a contiguous range and the
+//    workgroups of an XCD walk it together; inside a slice tiles are rasterised in column blocks of PP_GROUP tiles.
+// ------------------------------------------------------------------------------------------------
+#include "gemm_common.h"
+
+#define PP_BM 256
+#define PP_BN 256
+#define PP_UNIT 16384
+#define PP_STAGE (4 * PP_UNIT)               // AH0 AH1 BH0 BH1
+#define PP_LDS_BYTES (2 * PP_STAGE)
+#define PP_GROUP 4
+#define PP_OOB 0x80000000u                   // = num_records of the operand descriptors: any offset >= it reads zeros
+
+#define PP_WAITV(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+typedef __attribute__((ext_vector_type(4))) int pp_rsrc_t;
+
+__device__ __forceinline__ pp_rsrc_t pp_make_rsrc(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    pp_rsrc_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));      // stride 0: raw buffer
+    r[2] = (int)PP_OOB;
+    r[3] = 0x00020000;
+    return r;
+}
+// 16 B per lane: LDS[m0 + lane * 16] = mem[rsrc.base + soff + voff]  (zeros when voff >= num_records)
+__device__ __forceinline__ void pp_dma16(pp_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, %2 offen lds"
+                 :: "s"(rsrc), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(soff)),
+                    "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory");
+}
+
+// The parameter block re-read from the kernarg segment behind an opaque asm: values loaded through it cannot be kept
+// live across the K loop, which keeps the loop's scalar registers for the loop (hipcc otherwise parks dozens of epilogue
+// / work-list scalars in VGPR lanes and reads them back inside every phase).
+__device__ __forceinline__ const SmxGemmParams& pp_kernarg() {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const SmxGemmParams*)k;
+}
+
+struct PPItem {
+    int m0, n0, ks0, nk;
+    long long za, zb, zc, zbias, ze;
+};
+
+__device__ __forceinline__ void pp_decode(const SmxGemmParams& p, int q, int ntm, int ntn, int W, PPItem& it) {
+    const int nwg = ntm * ntn;
+    // XCD x (= q & 7 in dispatch order) owns a contiguous range of the work list (bijective for any W)
+    const int qq = W >> 3, r = W & 7, x = q & 7, y = q >> 3;
+    const int w = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + y;
+    const int z = w / nwg, lin = w - z * nwg;
+    const int per_group = PP_GROUP * ntm;
+    const int grp = lin / per_group, rem = lin - grp * per_group;
+    const int first = grp * PP_GROUP;
+    const int gsz = min(ntn - first, PP_GROUP);
+    const int tm = rem / gsz, tn = first + (rem - tm * gsz);
+    it.m0 = tm * PP_BM;
+    it.n0 = tn * PP_BN;
+    const int zb = z / p.split_k, zs = z - zb * p.split_k;
+    it.za = (long long)zb * p.batch_a;
+    it.zb = (long long)zb * p.batch_b;
+    it.zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride;
+    it.zbias = (long long)zb * p.batch_bias;
+    it.ze = (long long)zb * p.batch_e;
+    const int kst = (p.K + BK - 1) / BK;
+    const int per = (kst + p.split_k - 1) / p.split_k;
+    it.ks0 = zs * per;
+    it.nk = max(min(kst, it.ks0 + per) - it.ks0, 0);
+}
+
+// LDS images.  A units and all RC units use the 128x128 kernels' images (kc_addr / rc_addr).  KC B units swizzle
+// their 16-B chunks with pp_bswz so that the permuted fragment rows {8 (i>>2) + 4 j + (i & 3)} stay conflict-free.
+__device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+
+template <bool RC, bool IS_A>
+struct PPOperand {
+    pp_rsrc_t rsrc;
+    unsigned soff;          // scalar byte offset of the current K tile
+    unsigned sstep;         // its increment per K tile
+    unsigned voff[2][2];    // KC: [half][pass] byte offset of my (row, chunk);  RC: [0][pass] = my k-row, [1][half] = my columns
+    int kc;                 // KC: first k of my chunk inside a K tile;  RC: my k-row inside a K tile (pass 0)
+    int rt[2], rb[2];       // RC through a batched view: my k-row as (row inside batch, batch), per pass
+    int rpb;                // RC: rows per batch of the view (0: plain rows)
+
+    static __device__ __forceinline__ int grow(int h, int hr) {      // unit-local row -> tile row
+        if (IS_A) return (hr >> 6) * 128 + h * 64 + (hr & 63);
+        return (hr >> 5) * 64 + h * 32 + (hr & 31);
+    }
+    __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& v, int row0, int nrows, int k0, int tid) {
+        rsrc = pp_make_rsrc(b);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (!RC) {
+            soff = (unsigned)k0 * 2u;
+            sstep = BK * 2u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int hr = ps * 64 + wave * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ (IS_A ? ((hr >> 1) & 7) : pp_bswz(hr));
+                    kc = c * 8;
+                    const int r = row0 + grow(h, hr);
+                    voff[h][ps] = r < nrows ? (unsigned)(view_off(v, r) + c * 8) * 2u : PP_OOB;
+                }
+        } else {
+            const int kl = wave * 4 + (lane >> 4), g16 = lane & 15;      // rc_swz(kl) is the same for both passes
+            kc = kl;
+            const int hc = ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = row0 + grow(h, hc);
+                voff[1][h] = c < nrows ? (unsigned)c * 2u : PP_OOB;
+            }
+            rpb = v.rows_per_batch > 0 ? v.rows_per_batch : 0;
+            if (v.rows_per_batch > 0) {
+                soff = 0; sstep = 0;
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int k = k0 + ps * 32 + kl;
+                    rb[ps] = k / v.rows_per_batch;
+                    rt[ps] = k - rb[ps] * v.rows_per_batch;
+                }
+                view_rows(v);
+            } else {
+                soff = (unsigned)((long long)k0 * v.ld * 2);
+                sstep = (unsigned)(v.ld * BK * 2);
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) voff[0][ps] = (unsigned)((v.off + (long long)(ps * 32 + kl) * v.ld) * 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void view_rows(const SmxRowView& v) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            voff[0][ps] = (unsigned)((v.off + (long long)rb[ps] * v.batch_stride + (long long)rt[ps] * v.ld) * 2);
+    }
+    // unit H of the K tile whose first k is k0 -> LDS at byte address lds (wave-uniform part added here)
+    template <int H>
+    __device__ __forceinline__ void issue(unsigned lds, int k0, int K, int wave_u) const {
+        const bool tail = k0 + BK > K;                // uniform: only the last K tile of an operand pays for the selects
+        if (!RC) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                unsigned vo = voff[H][ps];
+                if (tail && k0 + kc >= K) vo = PP_OOB;
+                pp_dma16(rsrc, vo, soff, lds + (ps * 64 + wave_u * 8) * 128);
+            }
+        } else {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                unsigned vo = voff[0][ps] + voff[1][H];       // column part is PP_OOB when out of range: the sum stays >= 2^31
+                if (tail && k0 + ps * 32 + kc >= K) vo = PP_OOB;
+                pp_dma16(rsrc, vo, soff, lds + (ps * 32 + wave_u * 4) * 256);
+            }
+        }
+    }
+    __device__ __forceinline__ void advance() {
+        soff += sstep;
+        if (RC && rpb > 0) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                rt[ps] += BK;
+                while (rt[ps] >= rpb) { rt[ps] -= rpb; rb[ps] += 1; }
+            }
+            view_rows(IS_A ? pp_kernarg().a : pp_kernarg().b);
+        }
+    }
+};
+
+// Issue side of the flat unit stream: runs six units ahead of the compute side over the same (item, K tile) sequence.
+template <bool A_RC, bool B_RC>
+struct PPIssue {
+    PPOperand<A_RC, true> a;
+    PPOperand<B_RC, false> b;
+    int q, qstep, W, ntm, ntn;
+    int kt, nk, k0, seq, wave_u, K;
+    unsigned lds0;          // LDS byte address of the stage buffers
+    bool live;
+
+    __device__ __forceinline__ void load_item(int tid) {
+        live = q < W;
+        if (!live) return;
+        const SmxGemmParams& p = pp_kernarg();
+        PPItem it;
+        pp_decode(p, q, ntm, ntn, W, it);
+        k0 = it.ks0 * BK;
+        nk = it.nk;                       // >= 1: the launcher rejects split counts that leave a slice empty
+        kt = 0;
+        a.init(reinterpret_cast<const bf16_t*>(p.A) + it.za, p.a, it.m0, p.M, k0, tid);
+        b.init(reinterpret_cast<const bf16_t*>(p.B) + it.zb, p.b, it.n0, p.N, k0, tid);
+    }
+    // KIND: 0 AH0, 1 BH0, 2 BH1, 3 AH1 (then move to the next K tile).  Returns false when the stream has ended.
+    template <int KIND>
+    __device__ __forceinline__ bool issue(int tid) {
+        if (!live) return false;
+        const unsigned st = lds0 + (unsigned)(seq & 1) * PP_STAGE;
+        if (KIND == 0) a.template issue<0>(st + 0 * PP_UNIT, k0, K, wave_u);
+        else if (KIND == 1) b.template issue<0>(st + 2 * PP_UNIT, k0, K, wave_u);
+        else if (KIND == 2) b.template issue<1>(st + 3 * PP_UNIT, k0, K, wave_u);
+        else {
+            a.template issue<1>(st + 1 * PP_UNIT, k0, K, wave_u);
+            ++seq;
+            if (++kt == nk) {
+                q += qstep;
+                load_item(tid);
+            } else {
+                k0 += BK;
+                a.advance();
+                b.advance();
+            }
+        }
+        return true;
+    }
+};
+
+// B fragment j (0/1) of a 32-column half for the wave-column block starting at unit row r32: fragment column i of lane
+// i <-> logical column 8 (i >> 2) + 4 j + (i & 3)
+template <bool RC>
+__device__ __forceinline__ bf16x8_t pp_bfrag(const char* unit, int r32, int j, int kk, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    union { bf16x8_t v; uint4 u; uint2 h[2]; } f;
+    if (!RC) {
+        const int row = r32 + 8 * (i >> 2) + 4 * j + (i & 3);
+        f.u = *reinterpret_cast<const uint4*>(unit + row * 128 + (((kk * 4 + g) ^ pp_bswz(row)) << 4));
+    } else {
+        const int q = i >> 2, col = r32 + 8 * (i & 3) + 4 * j;
+        const int kb = kk * 32 + 8 * g + q;
+        f.h[0] = lds_tr_b64(unit + rc_addr(kb, col));
+        f.h[1] = lds_tr_b64(unit + rc_addr(kb + 4, col));
+    }
+    return f.v;
+}
+
+template <int PH, bool A_RC, bool B_RC, int LAB>
+__device__ __forceinline__ void pp_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4][2],
+                                         bf16x8_t (&fb0)[2][2], bf16x8_t (&fb1)[2][2], PPIssue<A_RC, B_RC>& is,
+                                         const char* cur, int tid, int lane, int wr, int wc, int wmode) {
+    // LAB (ablation builds only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 16 no epilogue
+    // ---- load segment: register sub-tile reads + one unit of LDS-DMA, then the counted wait for the NEXT phase's unit
+    if constexpr (!(LAB & 2)) {
+        if (PH == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb0[j][kk] = pp_bfrag<B_RC>(cur + 2 * PP_UNIT, wc * 32, j, kk, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (PH == 0 || PH == 2) {
+            const char* ha = cur + (PH == 0 ? 0 : 1) * PP_UNIT;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[a][kk] = load_frag<A_RC>(ha, wr * 64 + a * 16, kk, lane, 1);
+        }
+        if (PH == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fb1[j][kk] = pp_bfrag<B_RC>(cur + 3 * PP_UNIT, wc * 32, j, kk, lane);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(LAB & 1)) {
+        // wmode 0: counted wait.  1: this item's last phase - drain, so that the epilogue's stores (same counter, in-order)
+        // do not sit between the prefetched units and the waits that retire them.  2: first K tile after a drain - the
+        // units these four phases would retire were covered by it.
+        const bool issued = is.template issue<(PH + 2) & 3>(tid);
+        if (wmode == 2) {
+        } else if (issued && wmode == 0) {
+            PP_WAITV(8);
+        } else {
+            PP_WAITV(0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- compute segment: one quadrant x K = 64
+    constexpr int rh = PH >> 1, ch = (PH == 1 || PH == 2) ? 1 : 0;
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(LAB & 4))
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8_t bfrag;
+                if constexpr (ch == 1) bfrag = fb1[j][kk]; else bfrag = fb0[j][kk];
+                acc[rh * 4 + a][ch * 2 + j] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, fa[a][kk], acc[rh * 4 + a][ch * 2 + j], 0, 0, 0);
+            }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+// acc[rh*4+a][2 ch + j][r]: row mw0 + rh*64 + a*16 + (lane & 15), column nw0 + ch*32 + 8 (lane >> 4) + 4 j + r
+__device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[8][4], int mw0, int nw0, long long zc, long long zbias,
+                                            long long ze, int lane) {
+    const SmxGemmParams& p = pp_kernarg();
+    const int i16 = lane & 15, g = lane >> 4;
+    float bs[2][8];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const int n = nw0 + ch * 32 + g * 8;
+        if (p.bias && n + 8 <= p.N && !((zbias + n) & 3)) {
+            load8(p.bias + zbias + n, bs[ch]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[ch][e] = (p.bias && n + e < p.N) ? p.bias[zbias + n + e] : 0.f;
+        }
+        // Consume the bias right here: a load hipcc still tracks as pending when the next K loop starts makes it drain
+        // the whole VMEM queue (LDS-DMA prefetches included) before the first LDS read of every K tile.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bs[ch][e]));
+    }
+    const unsigned th = smx_thresh24(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    // rolled over the 16 (row block, column half) pieces - ONE copy of the row epilogue in the binary; the accumulators
+    // are picked by a wave-uniform switch so that every register index stays static
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < 16; ++it) {
+        float x[8], b8[8];
+#define PP_GET(A, C)                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) b8[e] = bs[C][e];                                      \
+    x[0] = acc[A][2 * C][0]; x[1] = acc[A][2 * C][1]; x[2] = acc[A][2 * C][2]; x[3] = acc[A][2 * C][3];  \
+    x[4] = acc[A][2 * C + 1][0]; x[5] = acc[A][2 * C + 1][1]; x[6] = acc[A][2 * C + 1][2]; x[7] = acc[A][2 * C + 1][3];
+        switch (it) {
+            case 0: PP_GET(0, 0) break;  case 1: PP_GET(0, 1) break;  case 2: PP_GET(1, 0) break;  case 3: PP_GET(1, 1) break;
+            case 4: PP_GET(2, 0) break;  case 5: PP_GET(2, 1) break;  case 6: PP_GET(3, 0) break;  case 7: PP_GET(3, 1) break;
+            case 8: PP_GET(4, 0) break;  case 9: PP_GET(4, 1) break;  case 10: PP_GET(5, 0) break; case 11: PP_GET(5, 1) break;
+            case 12: PP_GET(6, 0) break; case 13: PP_GET(6, 1) break; case 14: PP_GET(7, 0) break; default: PP_GET(7, 1) break;
+        }
+#undef PP_GET
+        const int a8 = it >> 1, ch = it & 1;
+        const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
+        const int n = nw0 + ch * 32 + g * 8;
+        if (m < p.M && n < p.N) epilogue_row8<true>(p, zc, ze, m, n, x, b8, th, inv_keep);
+    }
+}
+
+// ---- fast epilogues: fully unrolled, specialised at compile time by class, taken when every 16-B access is aligned
+// (checked per launch, wave-uniform); anything else goes through the rolled generic epilogue above.
+//   EPI 0 "linear":  C = bf16(alpha acc + bias) [x dropout] [+ resid]
+//   EPI 1 "act":     aux_out = bf16(pre) ; C = bf16(act(pre)) [x dropout]          (pre = alpha acc + bias)
+//   EPI 2 "actgrad": C = bf16(pre x act'(aux_in)) [x dropout]
+//   EPI 3 "f32":     C(fp32) = pre [+ C when atomic == 2]                            (weight gradients, split-K slabs)
+// Side inputs of 8 row pieces are loaded together BEFORE the first store of the group: hipcc waits for its own loads with
+// counts that do not know about the inline-asm stores, so a load issued behind a store would wait for that store too.
+enum { PP_EPI_LINEAR = 0, PP_EPI_ACT = 1, PP_EPI_ACTGRAD = 2, PP_EPI_F32 = 3 };
+
+__device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
+    const long long m = p.c.ld | p.c.off | p.c.batch_stride | p.e.ld | p.e.off | p.e.batch_stride | p.batch_c | p.batch_e |
+                        p.split_stride | p.batch_bias;
+    return !(m & 7) && !(p.N & 7);
+}
+
+template <int EPI>
+__device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, int nw0, long long zc, long long zbias,
+                                                 long long ze, int lane) {
+    const SmxGemmParams& p = pp_kernarg();
+    const int i16 = lane & 15, g = lane >> 4;
+    const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
+    float bs[2][8];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const int n = nl + ch * 32;
+        if (p.bias && n < p.N) {
+            load8(p.bias + zbias + n, bs[ch]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bs[ch][e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bs[ch][e]));      // consumed here (see pp_epilogue)
+    }
+    const unsigned th = smx_thresh24(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    const bool drop = p.drop_p > 0.f;
+    const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
+    const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
+    constexpr int GA = EPI == PP_EPI_F32 ? 2 : 4;     // row blocks per group (x 2 halves = pieces whose side inputs are in flight)
+#pragma unroll
+    for (int grp = 0; grp < 8 / GA; ++grp) {
+        long long cb[GA], eb[GA];
+        bool rok[GA];
+        uint4 side[GA][2];
+        float4 accum[GA][2][2];
+#pragma unroll
+        for (int a = 0; a < GA; ++a) {
+            const int a8 = grp * GA + a;
+            const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
+            rok[a] = m < p.M;
+            const int mm = rok[a] ? m : 0;
+            cb[a] = zc + view_off(p.c, mm) + nl;
+            eb[a] = (EPI == PP_EPI_F32) ? 0 : ze + view_off(p.e, mm) + nl;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const bool ok = rok[a] && nl + ch * 32 < p.N;
+                if (EPI == PP_EPI_ACTGRAD) {
+                    if (ok) side[a][ch] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + eb[a] + ch * 32);
+                } else if (EPI == PP_EPI_LINEAR) {
+                    if (has_res && ok) side[a][ch] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + eb[a] + ch * 32);
+                } else if (EPI == PP_EPI_F32) {
+                    if (has_acc && ok) {
+                        const float* c = reinterpret_cast<const float*>(p.C) + cb[a] + ch * 32;
+                        accum[a][ch][0] = *reinterpret_cast<const float4*>(c);
+                        accum[a][ch][1] = *reinterpret_cast<const float4*>(c + 4);
+                    }
+                }
+            }
+        }
+        // every side input is consumed HERE on every path: a load hipcc still tracks as pending when the next K loop
+        // starts makes it drain the whole VMEM queue before the first LDS read of every K tile
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                if (EPI == PP_EPI_ACTGRAD || EPI == PP_EPI_LINEAR)
+                    asm volatile("" : "+v"(side[a][ch].x), "+v"(side[a][ch].y), "+v"(side[a][ch].z), "+v"(side[a][ch].w));
+                if (EPI == PP_EPI_F32)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        asm volatile("" : "+v"(accum[a][ch][h].x), "+v"(accum[a][ch][h].y), "+v"(accum[a][ch][h].z),
+                                     "+v"(accum[a][ch][h].w));
+            }
+#pragma unroll
+        for (int a = 0; a < GA; ++a) {
+            const int a8 = grp * GA + a;
+            const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int n = nl + ch * 32;
+                if (!(rok[a] && n < p.N)) continue;
+                float x[8] = {acc[a8][2 * ch][0], acc[a8][2 * ch][1], acc[a8][2 * ch][2], acc[a8][2 * ch][3],
+                              acc[a8][2 * ch + 1][0], acc[a8][2 * ch + 1][1], acc[a8][2 * ch + 1][2], acc[a8][2 * ch + 1][3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[ch][e]);
+                if (EPI == PP_EPI_F32) {
+                    if (has_acc) {
+                        x[0] += accum[a][ch][0].x; x[1] += accum[a][ch][0].y; x[2] += accum[a][ch][0].z; x[3] += accum[a][ch][0].w;
+                        x[4] += accum[a][ch][1].x; x[5] += accum[a][ch][1].y; x[6] += accum[a][ch][1].z; x[7] += accum[a][ch][1].w;
+                    }
+                    st8<true>(reinterpret_cast<float*>(p.C) + cb[a] + ch * 32, x);
+                    continue;
+                }
+                if (EPI == PP_EPI_ACT) {
+                    if (p.aux_out) st8<true>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[a] + ch * 32, x);
+                    act_fwd8(x, p.act);
+                }
+                if (EPI == PP_EPI_ACTGRAD) {
+                    const uint4 u = side[a][ch];
+                    float s[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                  __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                    act_grad_mul8(x, s, p.act);
+                }
+                if (drop) {
+                    const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
+                }
+                if (EPI == PP_EPI_LINEAR && has_res) {
+                    const uint4 u = side[a][ch];
+                    x[0] += __uint_as_float(u.x << 16); x[1] += __uint_as_float(u.x & 0xffff0000u);
+                    x[2] += __uint_as_float(u.y << 16); x[3] += __uint_as_float(u.y & 0xffff0000u);
+                    x[4] += __uint_as_float(u.z << 16); x[5] += __uint_as_float(u.z & 0xffff0000u);
+                    x[6] += __uint_as_float(u.w << 16); x[7] += __uint_as_float(u.w & 0xffff0000u);
+                }
+                st8<true>(reinterpret_cast<bf16_t*>(p.C) + cb[a] + ch * 32, x);
+            }
+        }
+    }
+}
+
+template <bool A_RC, bool B_RC, int EPI, int LAB = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntm = (p.M + PP_BM - 1) / PP_BM, ntn = (p.N + PP_BN - 1) / PP_BN;
+    const int W = ntm * ntn * p.nbatch * p.split_k;
+
+    PPIssue<A_RC, B_RC> is;
+    is.q = blockIdx.x; is.qstep = gridDim.x; is.W = W; is.ntm = ntm; is.ntn = ntn;
+    is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
+    is.wave_u = __builtin_amdgcn_readfirstlane(wave);
+    is.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    is.K = p.K;
+    is.load_item(tid);
+
+    // prologue: K tile 0 entirely, AH0 + BH0 of K tile 1
+    if constexpr (!(LAB & 1)) {
+        bool all = true;
+        all &= is.template issue<0>(tid);
+        all &= is.template issue<1>(tid);
+        all &= is.template issue<2>(tid);
+        all &= is.template issue<3>(tid);
+        all &= is.template issue<0>(tid);
+        all &= is.template issue<1>(tid);
+        if (all) PP_WAITV(8);
+        else PP_WAITV(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // second wave-row group runs one barrier behind
+
+    f32x4_t acc[8][4];
+    bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+    if constexpr ((LAB & 2) != 0) {
+        for (int a = 0; a < 4; ++a) for (int k = 0; k < 2; ++k) fa[a][k] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = 0; a < 2; ++a) for (int k = 0; k < 2; ++k) fb0[a][k] = fb1[a][k] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    int seq = 0;
+    bool drained = false;
+    // the launcher sets bit 7 of tr_mode when the parameters fit this instantiation's epilogue class
+    const bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
+    for (int q = blockIdx.x; q < W; q += gridDim.x) {
+        PPItem it;
+        pp_decode(pp_kernarg(), q, ntm, ntn, W, it);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < it.nk; ++t) {
+            const char* cur = smem + (seq & 1) * PP_STAGE;
+            const int w0 = (t == 0 && drained) ? 2 : 0;
+            const int w3 = (t == it.nk - 1) ? 1 : w0;
+            pp_phase<0, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
+            pp_phase<1, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
+            pp_phase<2, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
+            pp_phase<3, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w3);
+            ++seq;
+        }
+        drained = it.nk > 0;
+        if constexpr ((LAB & 16) != 0) {
+            float sink = 0.f;
+            for (int a = 0; a < 8; ++a) for (int j = 0; j < 4; ++j) sink += acc[a][j][0] + acc[a][j][1] + acc[a][j][2] + acc[a][j][3];
+            if (sink == 1234.5f) reinterpret_cast<float*>(p.C)[tid] = sink;
+        } else if (fast_epi) {
+            pp_epilogue_fast<EPI>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane);
+        } else {
+            pp_epilogue(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane);
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+}
+
+// epilogue class of a parameter block, or -1 when only the generic epilogue applies
+static int pp_epi_class(const SmxGemmParams& p) {
+    if (p.out_f32) return (p.aux_in || p.aux_out || p.resid || p.act || p.drop_p > 0.f) ? -1 : PP_EPI_F32;
+    if (p.atomic) return -1;
+    if (p.aux_in) return (p.resid || p.aux_out) ? -1 : PP_EPI_ACTGRAD;
+    if (p.act || p.aux_out) return p.resid ? -1 : PP_EPI_ACT;
+    return PP_EPI_LINEAR;
+}
+
+template <bool A_RC, bool B_RC, int EPI>
+static void pp_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<A_RC, B_RC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<A_RC, B_RC, EPI>), grid, dim3(512), PP_LDS_BYTES, stream, p);
+}
+
+int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
+    SmxGemmParams p = pin;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+        ncu &= ~7;
+    }
+    const long long W = (long long)((p.M + PP_BM - 1) / PP_BM) * ((p.N + PP_BN - 1) / PP_BN) * p.nbatch * p.split_k;
+    const int kst = (p.K + BK - 1) / BK, per = (kst + p.split_k - 1) / p.split_k;
+    // fp32 atomics: 128x128 kernels only; every K slice must own at least one K tile; K in whole 16-B chunks
+    if (W > 0x7fffffffLL || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
+        ((p.K & 7) && !(p.a_rc && p.b_rc))) return SMX_EINVAL;
+    dim3 grid((unsigned)(W < ncu ? W : ncu));
+    const int lab = p.tr_mode >> 8;
+    const int epi = pp_epi_class(p);
+    p.tr_mode = 8;
+#ifdef SMX_PP_LAB
+    if (!p.a_rc && !p.b_rc && lab) {
+        const size_t ldsz = PP_LDS_BYTES;
+#define PP_LABV(L)                                                                                                          \
+    case L:                                                                                                                 \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<false, false, 0, L>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm_bf16_pp_kernel<false, false, 0, L>), grid, dim3(512), ldsz, stream, p);                   \
+        break;
+        switch (lab) {
+            PP_LABV(16) PP_LABV(17) PP_LABV(18) PP_LABV(19)
+            default: return SMX_EINVAL;
+        }
+        SMX_CHECK_LAUNCH();
+    }
+#endif
+    (void)lab;
+    // instantiated (layout, class) pairs; other combinations run a sibling with the generic epilogue
+#define PP_GO(AR, BR, E) { if (epi == E) p.tr_mode |= 128; pp_launch<AR, BR, E>(p, grid, stream); SMX_CHECK_LAUNCH(); }
+    if (!p.a_rc && !p.b_rc) {
+        if (epi == PP_EPI_ACT) PP_GO(false, false, PP_EPI_ACT)
+        if (epi == PP_EPI_F32) PP_GO(false, false, PP_EPI_F32)
+        PP_GO(false, false, PP_EPI_LINEAR)
+    }
+    if (!p.a_rc && p.b_rc) {
+        if (epi == PP_EPI_ACTGRAD) PP_GO(false, true, PP_EPI_ACTGRAD)
+        if (epi == PP_EPI_F32) PP_GO(false, true, PP_EPI_F32)
+        PP_GO(false, true, PP_EPI_LINEAR)
+    }
+    if (p.a_rc && p.b_rc) PP_GO(true, true, PP_EPI_F32)
+    PP_GO(true, false, PP_EPI_F32)
+#undef PP_GO
+}

@@ -45,6 +45,7 @@ class Engine:
         self.downloop = int(math.log(down_scale, 2)) if down_scale > 1 else 0
         self.ep, self.lp = enc_prefix, lm_prefix
         self._persist: Dict[str, torch.Tensor] = {}
+        self._wgrad_pick: Dict[tuple, int] = {}     # tuned (kernel, K split) choice per weight-gradient shape
         self.saved = None
         rank = int(os.environ.get("RANK", "0"))         # independent draws per data-parallel rank
         self.rng = np.random.default_rng(rank)
@@ -145,22 +146,66 @@ class Engine:
                    resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
         return dx
 
+    def _wgrad_gemm(self, dy, x, out, No, Ko, Kred, av, bv, alpha, accumulate, cv=None, **kw):
+        """out[No,Ko] (+)= dy^T x over Kred rows.  Two candidate launches - the 128x128 kernel with its K split and the
+        ping-pong kernel with a split sized for one round of 256x256 items - timed on first use per shape (both write
+        slabs, so the trial runs are side-effect free); the slab sum then lands in `out`."""
+        n = No * Ko
+        cands = [(1, self._split(No, Ko, Kred))]
+        if self.dt == BF16 and ops.PP_MODE != "0" and cv is None:
+            sp = ops.pp_split(No, Ko, Kred)
+            if ((No + 255) // 256) * ((Ko + 255) // 256) * sp >= 96 and sp > 1:
+                cands.append((8, sp))
+        if len(cands) > 1 and ops.PP_MODE == "1":
+            cands = cands[1:]
+
+        def run(mode, split):
+            if split <= 1:
+                ops.gemm(dy, x, out, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True,
+                         atomic=2 if accumulate else 0, alpha=alpha, tr_mode=mode, **kw)
+                return
+            slabs = self.workspace("wgrad_slabs", split * n, torch.float32)
+            ops.gemm(dy, x, slabs, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True, atomic=0,
+                     split_k=split, split_stride=n, alpha=alpha, tr_mode=mode, **kw)
+            ops.reduce_slabs(slabs, split, n, n, out, accumulate=accumulate)
+
+        pick = 0
+        if len(cands) > 1:
+            key = ("wgrad", No, Ko, Kred, av.rows_per_batch > 0, bv.rows_per_batch > 0, tuple(sorted(kw)))
+            pick = self._wgrad_pick.get(key)
+            if pick is None:
+                pick = 0
+                if all(sp > 1 for _, sp in cands):          # slab launches only: re-running them changes nothing
+                    ts = []
+                    for mode, sp in cands:
+                        slabs = self.workspace("wgrad_slabs", sp * n, torch.float32)
+
+                        def once():
+                            ops.gemm(dy, x, slabs, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True,
+                                     atomic=0, split_k=sp, split_stride=n, alpha=alpha, tr_mode=mode, **kw)
+                            ops.reduce_slabs(slabs, sp, n, n, slabs, accumulate=False)
+                        once()
+                        torch.cuda.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(3):
+                            once()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    pick = 1 if ts[1] < 0.97 * ts[0] else 0
+                    if ops.TUNE_LOG is not None:
+                        ops.TUNE_LOG.append((key, ts[0] / 3, ts[1] / 3, cands[pick]))
+                self._wgrad_pick[key] = pick
+        run(*cands[pick])
+
     def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, **kw):
         """gw[N,K] += dy[M,N]^T @ x[M,K];  gb[N] += colsum(dy).  The reduction over M is split across workgroups
         when the output has too few tiles to fill the chip: each split stores its fp32 partial slab and one
         streaming pass sums the slabs into the gradient (no atomics: they serialise in L2)."""
-        split = self._split(N, K, M)
         av = dyv if dyv is not None else view(N)
         bv = xv if xv is not None else view(K)
-        if split <= 1:
-            ops.gemm(dy, x, gw, N, K, M, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, out_f32=True, atomic=2, alpha=alpha,
-                     **kw)
-        else:
-            n = N * K
-            slabs = self.workspace("wgrad_slabs", split * n, torch.float32)
-            ops.gemm(dy, x, slabs, N, K, M, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, out_f32=True, atomic=0,
-                     split_k=split, split_stride=n, alpha=alpha, **kw)
-            ops.reduce_slabs(slabs, split, n, n, gw, accumulate=True)
+        self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
         if gb is not None:
             ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha)
 

@@ -5,6 +5,7 @@ happens in the hand-written HIP kernels.  There is no PyTorch/CPU fallback: a mi
 non-GPU tensor or a non-zero return code raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -55,19 +56,96 @@ def _gemm_params(a, b, c, M, N, K, a_rc=False, b_rc=False, av=None, bv=None, cv=
     return p
 
 
+# ---- kernel choice for bf16 GEMMs --------------------------------------------------------------------------------
+# Two hand-written kernels serve every bf16 GEMM: the 128x128 LDS-DMA kernel at 4 workgroups/CU (tr_mode 1) and the
+# persistent 256x256 ping-pong kernel (tr_mode 8, csrc/gemm_pp.hip).  Which one is faster depends on the shape (tile
+# quantisation over 256 CUs, K tiles per output tile, epilogue weight), so the first launch of every distinct
+# (layout, shape, epilogue) key times both on the live operands and the winner is cached for the rest of the process.
+# SMX_GEMM_PP = auto (default) | 0 (128x128 only) | 1 (ping-pong whenever it is applicable).
+PP_MODE = os.environ.get("SMX_GEMM_PP", "auto")
+_TUNED = {}
+
+
+def _pp_applicable(p, dtype):
+    if dtype != BF16 or p.atomic == 1 or p.M < 256 or p.N < 64:
+        return False
+    if (p.K & 7) and not (p.a_rc and p.b_rc):
+        return False
+    kst = (p.K + 63) // 64
+    per = (kst + p.split_k - 1) // p.split_k
+    if (p.split_k - 1) * per >= kst:
+        return False
+    items = ((p.M + 255) // 256) * ((p.N + 255) // 256) * p.nbatch * p.split_k
+    return items >= 96                     # fewer work items than that cannot occupy the chip with one workgroup per CU
+
+
+def _launch(p, dtype):
+    L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+
+
+def _time_mode(p, dtype, mode, reps=3):
+    p.tr_mode = mode
+    _launch(p, dtype)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _launch(p, dtype)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _choose_mode(p, dtype):
+    """-> tr_mode for this launch (1 or 8)."""
+    if PP_MODE == "0" or not _pp_applicable(p, dtype):
+        return 1
+    if PP_MODE == "1":
+        return 8
+    key = (p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
+           p.act, p.out_f32, p.atomic, p.drop_p > 0, p.a.rows_per_batch > 0, p.b.rows_per_batch > 0, p.c.rows_per_batch > 0)
+    mode = _TUNED.get(key)
+    if mode is None:
+        # re-running the launch must not change the result: no accumulation into C, no side input aliasing the output
+        safe = p.atomic == 0 and p.resid != p.C and p.aux_in != p.C and p.A != p.C and p.B != p.C
+        mode = 1
+        if safe:
+            t1, t8 = _time_mode(p, dtype, 1), _time_mode(p, dtype, 8)
+            mode = 8 if t8 < 0.97 * t1 else 1
+            if TUNE_LOG is not None:
+                TUNE_LOG.append((key, t1, t8, mode))
+        _TUNED[key] = mode
+    return mode
+
+
+TUNE_LOG = None      # set to a list to record (key, ms_128, ms_pp, choice) of every tuning decision
+
+
 def gemm(a, b, c, M, N, K, dtype, **kw):
     """C[M,N] (+)= epi(alpha * A B^T).  a/b/c are tensors (base pointers); av/bv/cv are RowViews in elements.
-    drop = (p, seed): dropout after the activation (before the residual add); mask index = m * N + n."""
+    drop = (p, seed): dropout after the activation (before the residual add); mask index = m * N + n.
+    tr_mode: kernel variant; omit it to let the bf16 path choose between the 128x128 and the ping-pong kernel."""
     p = _gemm_params(a, b, c, M, N, K, **kw)
+    if "tr_mode" not in kw:
+        p.tr_mode = _choose_mode(p, dtype)
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = prof.events()
         e0.record()
-        L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+        _launch(p, dtype)
         e1.record()
-        prof.add((p.a_rc, p.b_rc), e0, e1, 2.0 * M * N * K * p.nbatch, (M, N, K, p.nbatch, p.split_k))
+        prof.add((p.a_rc, p.b_rc, p.tr_mode & 255), e0, e1, 2.0 * M * N * K * p.nbatch, (M, N, K, p.nbatch, p.split_k))
         return
-    L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
+    _launch(p, dtype)
+
+
+def pp_split(Mo, No, Kred):
+    """K-slice count for a weight-gradient GEMM on the ping-pong kernel: one round of 256x256 work items over the CUs."""
+    tiles = ((Mo + 255) // 256) * ((No + 255) // 256)
+    ksteps = (Kred + 63) // 64
+    want = max(1, min(256 // max(tiles, 1), ksteps // 4))
+    per = (ksteps + want - 1) // want
+    return (ksteps + per - 1) // per
 
 
 def gemm_splitk(a, b, c, M, N, K, dtype, split, slabs, **kw):
@@ -86,8 +164,13 @@ def gemm_splitk(a, b, c, M, N, K, dtype, split, slabs, **kw):
 class GemmProfile:
     """Live per-launch timing of the GEMM kernel variants with HIP events on the launch stream (bench.py).
     Variants: (a_rc, b_rc) = (0,0) forward, (0,1) data gradient, (1,1) weight gradient."""
-    NAMES = {(0, 0): "gemm_bf16_dma_kernel<false,false> (fwd)", (0, 1): "gemm_bf16_dma_kernel<false,true> (dgrad)",
-             (1, 1): "gemm_bf16_dma_kernel<true,true> (wgrad)", (1, 0): "gemm_bf16_dma_kernel<true,false>"}
+    _ROLE = {(0, 0): "fwd", (0, 1): "dgrad", (1, 1): "wgrad", (1, 0): "rc_kc"}
+
+    @staticmethod
+    def name(key):
+        a, b, mode = key
+        kern = "gemm_bf16_pp_kernel" if mode == 8 else "gemm_bf16_dma_kernel"
+        return f"{kern}<{str(bool(a)).lower()},{str(bool(b)).lower()}> ({GemmProfile._ROLE[(a, b)]})"
 
     def __init__(self):
         self.pool, self.used, self.recs = [], 0, []

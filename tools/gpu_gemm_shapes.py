@@ -12,6 +12,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", share_layer_ratio=0, down_scale=2, compute_dtype="bf16")
 model.eval()
 runner = StepRunner(model)
+ops.TUNE_LOG = []
 wave, labels = synth_batch(32, model.decoder_model.config.vocab_size, 0, torch.device("cuda:0"))
 for _ in range(2):
     runner.step(wave, labels)
@@ -25,7 +26,12 @@ rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["total_ms"])
 tot = sum(d["total_ms"] for _, d in rows) / steps
 print(f"GEMM total {tot:.2f} ms/step")
 names = {(0, 0): "fwd  ", (0, 1): "dgrad", (1, 1): "wgrad", (1, 0): "rc_kc"}
+names = {(a, b, m): n + ("/pp " if m == 8 else "/128") for (a, b), n in names.items() for m in (0, 1, 4, 8)}
 for (var, shape), d in rows[:60]:
     M, N, K, nb, sk = shape
     print(f"{d['total_ms']/steps:7.3f} ms/step {d['launches']/steps:5.1f}x avg {1e3*d['total_ms']/d['launches']:8.1f} us "
           f"{d['flops']/d['total_ms']/1e9:7.1f} TF/s  {names[var]} M={M:7d} N={N:6d} K={K:7d} nb={nb} split={sk}")
+
+print("\n# kernel choices (ms 128x128, ms ping-pong, pick)")
+for key, t1, t8, mode in sorted(ops.TUNE_LOG, key=lambda r: -max(r[1], r[2])):
+    print(f"{t1*1e3:8.1f} us {t8*1e3:8.1f} us -> {mode}   {key[:7]}")
