@@ -100,6 +100,9 @@ int smx_cross_entropy(const SmxCEParams* p, int dtype, hipStream_t stream);
 int smx_embed_fwd(const long long* ids, const void* table, void* out, int M, int D, float scale, int dtype, hipStream_t stream);
 int smx_embed_bwd(const long long* ids, const void* dy, float* dtable, int M, int D, float scale, int dtype, hipStream_t stream);
 int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream);
+/* same sum in two stages through a caller-owned scratch of smx_colsum_ws_floats(M, N) floats (no atomics; tall inputs) */
+long long smx_colsum_ws_floats(int M, int N);
+int smx_colsum_ws(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, float* ws, hipStream_t stream);
 int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream);
 int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k, int dtype, hipStream_t stream);

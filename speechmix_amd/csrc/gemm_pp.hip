@@ -73,29 +73,60 @@ struct PPItem {
     long long za, zb, zc, zbias, ze;
 };
 
-__device__ __forceinline__ void pp_decode(const SmxGemmParams& p, int q, int ntm, int ntn, int W, PPItem& it) {
-    const int nwg = ntm * ntn;
+// a / b for 0 <= a < 2^22, b >= 1, rb = 1.0f / b: one multiply and a one-step fix-up instead of the ~40-instruction
+// integer division (the work-list and row-view decodes run inside a load segment, with the partner group waiting)
+__device__ __forceinline__ int pp_fdiv(int a, int b, float rb) {
+    int q = (int)((float)a * rb);
+    const int r = a - q * b;
+    q += (r >= b) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+__device__ __forceinline__ long long pp_view_off(const SmxRowView& v, int r, float rrpb) {
+    if (v.rows_per_batch > 0) {
+        const int b = pp_fdiv(r, v.rows_per_batch, rrpb);
+        return v.off + (long long)b * v.batch_stride + (long long)(r - b * v.rows_per_batch) * v.ld;
+    }
+    return v.off + (long long)r * v.ld;
+}
+
+// reciprocals of the work-list divisors, computed once per workgroup
+struct PPDiv {
+    float r_nwg, r_pg, r_split;
+    int nwg, per_group, ntm, ntn, W, kst, per;
+    __device__ __forceinline__ void init(const SmxGemmParams& p, int ntm_, int ntn_) {
+        ntm = ntm_; ntn = ntn_;
+        nwg = ntm * ntn;
+        per_group = PP_GROUP * ntm;
+        W = nwg * p.nbatch * p.split_k;
+        r_nwg = 1.0f / (float)nwg;
+        r_pg = 1.0f / (float)per_group;
+        r_split = 1.0f / (float)p.split_k;
+        kst = (p.K + BK - 1) / BK;
+        per = (kst + p.split_k - 1) / p.split_k;
+    }
+};
+
+__device__ __forceinline__ void pp_decode(const SmxGemmParams& p, const PPDiv& d, int q, PPItem& it) {
     // XCD x (= q & 7 in dispatch order) owns a contiguous range of the work list (bijective for any W)
-    const int qq = W >> 3, r = W & 7, x = q & 7, y = q >> 3;
+    const int qq = d.W >> 3, r = d.W & 7, x = q & 7, y = q >> 3;
     const int w = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + y;
-    const int z = w / nwg, lin = w - z * nwg;
-    const int per_group = PP_GROUP * ntm;
-    const int grp = lin / per_group, rem = lin - grp * per_group;
+    const int z = pp_fdiv(w, d.nwg, d.r_nwg), lin = w - z * d.nwg;
+    const int grp = pp_fdiv(lin, d.per_group, d.r_pg), rem = lin - grp * d.per_group;
     const int first = grp * PP_GROUP;
-    const int gsz = min(ntn - first, PP_GROUP);
-    const int tm = rem / gsz, tn = first + (rem - tm * gsz);
+    const int gsz = min(d.ntn - first, PP_GROUP);                     // 1..4
+    const int tm = gsz == 4 ? rem >> 2 : gsz == 2 ? rem >> 1 : gsz == 1 ? rem : pp_fdiv(rem, 3, 1.0f / 3.0f);
+    const int tn = first + (rem - tm * gsz);
     it.m0 = tm * PP_BM;
     it.n0 = tn * PP_BN;
-    const int zb = z / p.split_k, zs = z - zb * p.split_k;
+    const int zb = pp_fdiv(z, p.split_k, d.r_split), zs = z - zb * p.split_k;
     it.za = (long long)zb * p.batch_a;
     it.zb = (long long)zb * p.batch_b;
     it.zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride;
     it.zbias = (long long)zb * p.batch_bias;
     it.ze = (long long)zb * p.batch_e;
-    const int kst = (p.K + BK - 1) / BK;
-    const int per = (kst + p.split_k - 1) / p.split_k;
-    it.ks0 = zs * per;
-    it.nk = max(min(kst, it.ks0 + per) - it.ks0, 0);
+    it.ks0 = zs * d.per;
+    it.nk = max(min(d.kst, it.ks0 + d.per) - it.ks0, 0);
 }
 
 // LDS images.  A units and all RC units use the 128x128 kernels' images (kc_addr / rc_addr).  KC B units swizzle
@@ -118,6 +149,7 @@ struct PPOperand {
     }
     __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& v, int row0, int nrows, int k0, int tid) {
         rsrc = pp_make_rsrc(b);
+        const float rrpb = 1.0f / (float)max(v.rows_per_batch, 1);
         const int lane = tid & 63, wave = tid >> 6;
         if (!RC) {
             soff = (unsigned)k0 * 2u;
@@ -130,7 +162,7 @@ struct PPOperand {
                     const int c = (lane & 7) ^ (IS_A ? ((hr >> 1) & 7) : pp_bswz(hr));
                     kc = c * 8;
                     const int r = row0 + grow(h, hr);
-                    voff[h][ps] = r < nrows ? (unsigned)(view_off(v, r) + c * 8) * 2u : PP_OOB;
+                    voff[h][ps] = r < nrows ? (unsigned)(pp_view_off(v, r, rrpb) + c * 8) * 2u : PP_OOB;
                 }
         } else {
             const int kl = wave * 4 + (lane >> 4), g16 = lane & 15;      // rc_swz(kl) is the same for both passes
@@ -147,7 +179,7 @@ struct PPOperand {
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
                     const int k = k0 + ps * 32 + kl;
-                    rb[ps] = k / v.rows_per_batch;
+                    rb[ps] = pp_fdiv(k, v.rows_per_batch, rrpb);
                     rt[ps] = k - rb[ps] * v.rows_per_batch;
                 }
                 view_rows(v);
@@ -202,17 +234,18 @@ template <bool A_RC, bool B_RC>
 struct PPIssue {
     PPOperand<A_RC, true> a;
     PPOperand<B_RC, false> b;
-    int q, qstep, W, ntm, ntn;
+    PPDiv dv;
+    int q, qstep;
     int kt, nk, k0, seq, wave_u, K;
     unsigned lds0;          // LDS byte address of the stage buffers
     bool live;
 
     __device__ __forceinline__ void load_item(int tid) {
-        live = q < W;
+        live = q < dv.W;
         if (!live) return;
         const SmxGemmParams& p = pp_kernarg();
         PPItem it;
-        pp_decode(p, q, ntm, ntn, W, it);
+        pp_decode(p, dv, q, it);
         k0 = it.ks0 * BK;
         nk = it.nk;                       // >= 1: the launcher rejects split counts that leave a slice empty
         kt = 0;
@@ -408,6 +441,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
     const bool drop = p.drop_p > 0.f;
+    const float rrc = 1.0f / (float)max(p.c.rows_per_batch, 1), rre = 1.0f / (float)max(p.e.rows_per_batch, 1);
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
     constexpr int GA = EPI == PP_EPI_F32 ? 2 : 4;     // row blocks per group (x 2 halves = pieces whose side inputs are in flight)
@@ -423,8 +457,8 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
             const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
             rok[a] = m < p.M;
             const int mm = rok[a] ? m : 0;
-            cb[a] = zc + view_off(p.c, mm) + nl;
-            eb[a] = (EPI == PP_EPI_F32) ? 0 : ze + view_off(p.e, mm) + nl;
+            cb[a] = zc + pp_view_off(p.c, mm, rrc) + nl;
+            eb[a] = (EPI == PP_EPI_F32) ? 0 : ze + pp_view_off(p.e, mm, rre) + nl;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const bool ok = rok[a] && nl + ch * 32 < p.N;
@@ -513,7 +547,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
     const int W = ntm * ntn * p.nbatch * p.split_k;
 
     PPIssue<A_RC, B_RC> is;
-    is.q = blockIdx.x; is.qstep = gridDim.x; is.W = W; is.ntm = ntm; is.ntn = ntn;
+    is.dv.init(p, ntm, ntn);
+    is.q = blockIdx.x; is.qstep = gridDim.x;
     is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
     is.wave_u = __builtin_amdgcn_readfirstlane(wave);
     is.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
     const bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
     for (int q = blockIdx.x; q < W; q += gridDim.x) {
         PPItem it;
-        pp_decode(pp_kernarg(), q, ntm, ntn, W, it);
+        pp_decode(pp_kernarg(), is.dv, q, it);
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -608,13 +643,16 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
     const long long W = (long long)((p.M + PP_BM - 1) / PP_BM) * ((p.N + PP_BN - 1) / PP_BN) * p.nbatch * p.split_k;
     const int kst = (p.K + BK - 1) / BK, per = (kst + p.split_k - 1) / p.split_k;
     // fp32 atomics: 128x128 kernels only; every K slice must own at least one K tile; K in whole 16-B chunks
-    if (W > 0x7fffffffLL || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
+    // (sizes below 2^22: the in-kernel index arithmetic divides through fp32 reciprocals)
+    if (W >= (1 << 22) || p.M >= (1 << 22) || p.N >= (1 << 22) || p.K >= (1 << 22) || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
         ((p.K & 7) && !(p.a_rc && p.b_rc))) return SMX_EINVAL;
     dim3 grid((unsigned)(W < ncu ? W : ncu));
     const int lab = p.tr_mode >> 8;
     const int epi = pp_epi_class(p);
     p.tr_mode = 8;
 #ifdef SMX_PP_LAB
+    if (lab == 32) { p.c.ld = 0; p.e.ld = 0; }       // every output row on top of row 0: same instructions, no write volume
+    else
     if (!p.a_rc && !p.b_rc && lab) {
         const size_t ldsz = PP_LDS_BYTES;
 #define PP_LABV(L)                                                                                                          \

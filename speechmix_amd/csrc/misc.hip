@@ -192,6 +192,82 @@ extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld,
     SMX_CHECK_LAUNCH();
 }
 
+// Two-stage column sum for tall matrices (the bias gradients of the encoder: M = 16 k rows).  The atomic version above
+// is limited by its handful of resident waves (the per-address fp32 atomics cap the number of row slices); here every
+// row slice writes one partial row into a workspace (no atomics), so the grid can cover the chip with 8 x 16-B loads
+// in flight per lane, and a second tiny launch folds the partial rows into out.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ x, float* __restrict__ ws, int M, int N,
+                                                          long long ld, int Np) {
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < N) {                                   // N % 8 == 0 on this path
+        const int step = gridDim.y * 4;
+        int m = blockIdx.y * 4 + w;
+        for (; m + 7 * step < M; m += 8 * step) {
+            float v[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load8(x + (long long)(m + u * step) * ld + c, v[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                acc[e] += ((v[0][e] + v[1][e]) + (v[2][e] + v[3][e])) + ((v[4][e] + v[5][e]) + (v[6][e] + v[7][e]));
+        }
+        for (; m < M; m += step) {
+            float v[8];
+            load8(x + (long long)m * ld + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[w][lane][e] = acc[e];
+    __syncthreads();
+    if (w == 0 && c < N) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+        store8(ws + (long long)blockIdx.y * Np + c, o);
+    }
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ ws, float* __restrict__ out, int parts, int N,
+                                                          int Np, float alpha) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a = 0.f;
+    if (c < N)
+        for (int r = w; r < parts; r += 4) a += ws[(long long)r * Np + c];
+    red[w][lane] = a;
+    __syncthreads();
+    if (w == 0 && c < N) out[c] += alpha * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+// out[n] += alpha * sum_m x[m, n].  ws: >= smx_colsum_ws_floats(M, N) floats of scratch, or null (atomic single-stage form).
+extern "C" long long smx_colsum_ws_floats(int M, int N) {
+    const int gx = (N + 511) / 512;
+    int gy = max(1, 1024 / gx);
+    if (gy > (M + 31) / 32) gy = (M + 31) / 32;
+    return (long long)gy * ((N + 7) / 8 * 8);
+}
+extern "C" int smx_colsum_ws(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, float* ws,
+                             hipStream_t stream) {
+    // measured (tools/gpu_colsum_bench.py): the two-stage form wins for the CNN's 10^5-row inputs only (151 vs 187 us at
+    // 511968 x 512); at the encoder's 16 k rows the second launch costs more than the atomics it removes
+    if (!ws || (N & 7) || M < 131072) return smx_colsum(x, out, M, N, ld, alpha, dtype, stream);
+    (void)hipGetLastError();
+    if (M <= 0 || N <= 0 || (ld & 7)) return SMX_EINVAL;
+    const int gx = (N + 511) / 512, Np = (N + 7) / 8 * 8;
+    int gy = max(1, 1024 / gx);                   // ~4 workgroups per CU
+    if (gy > (M + 31) / 32) gy = (M + 31) / 32;
+    dim3 grid(gx, gy);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, ws, M, N, ld, Np);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, ws, M, N, ld, Np);
+    else return SMX_EINVAL;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, out, gy, N, Np, alpha);
+    SMX_CHECK_LAUNCH();
+}
+
 // ---------------------------------------------------------------- cross entropy over the vocabulary
 // CrossEntropyLoss(ignore_index=-100, mean)  (TF:models/bart/modeling_bart.py:942-946) fused with
 // argmax (ref:speechmix/model.py:174) and the logits gradient.  One block per token row.

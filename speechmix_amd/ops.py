@@ -67,7 +67,7 @@ _TUNED = {}
 
 
 def _pp_applicable(p, dtype):
-    if dtype != BF16 or p.atomic == 1 or p.M < 256 or p.N < 64:
+    if dtype != BF16 or p.atomic == 1 or p.M < 256 or p.N < 64 or max(p.M, p.N, p.K) >= (1 << 22):
         return False
     if (p.K & 7) and not (p.a_rc and p.b_rc):
         return False
@@ -326,8 +326,22 @@ def embed_bwd(ids, dy, dtable, M, D, scale, dtype):
 
 
 def colsum(x, out, M, N, ld, dtype, alpha=1.0):
-    L.check(L.lib().smx_colsum(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_longlong(ld), C.c_float(alpha),
-                               dtype, _stream()), "smx_colsum")
+    """out[n] += alpha * sum_m x[m, n]; tall inputs go through the two-stage kernel with a cached scratch buffer."""
+    fn = L.lib().smx_colsum_ws_floats
+    fn.restype = C.c_longlong
+    need = int(fn(M, N))
+    ws = _COLSUM_WS.get(x.device)
+    if os.environ.get("SMX_COLSUM") == "atomic":          # A/B switch: single-stage atomic kernel
+        L.check(L.lib().smx_colsum(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_longlong(ld), C.c_float(alpha),
+                                   dtype, _stream()), "smx_colsum")
+        return
+    if ws is None or ws.numel() < need:
+        ws = _COLSUM_WS[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
+    L.check(L.lib().smx_colsum_ws(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_longlong(ld), C.c_float(alpha),
+                                  dtype, C.c_void_p(_ptr(ws)), _stream()), "smx_colsum_ws")
+
+
+_COLSUM_WS = {}
 
 
 def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, gscale=1.0, lse=None, logits_t=None,

@@ -11,6 +11,35 @@ def test_gemm_variants_views_epilogues_splitk():
     assert gpu_check_gemm.main() == 0
 
 
+def test_pingpong_gemm_matches_128_kernel_all_layouts_and_epilogues(capsys):
+    """256x256 persistent kernel (tr_mode 8) vs the 128x128 kernel on the model's shapes: fwd / dgrad / split-K wgrad,
+    conv row views, batched launches, every fast epilogue class and the generic one, repeated (race screen)."""
+    import sys
+    from tools import gpu_check_pp
+    argv, sys.argv = sys.argv, ["gpu_check_pp.py", "quick", "notime"]
+    try:
+        assert gpu_check_pp.main() == 0
+    finally:
+        sys.argv = argv
+    assert "FAIL" not in capsys.readouterr().out
+
+
+def test_colsum_two_stage_and_atomic():
+    import torch
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for (M, N, ld) in ((15968, 768, 768), (7968, 3072, 3072), (1024, 768, 768), (300, 50, 56), (4096, 512, 1536), (140000, 512, 512)):
+        x = torch.randn(M, ld, device=dev)
+        for dt, tdt, tol in ((ops.F32, torch.float32, 2e-5), (ops.BF16, torch.bfloat16, 2e-5)):
+            xx = x.to(tdt)
+            out = torch.full((N,), 0.5, dtype=torch.float32, device=dev)
+            ops.colsum(xx, out, M, N, ld, dt, alpha=0.25)
+            ref = 0.5 + 0.25 * xx[:, :N].double().sum(0)
+            err = (out.double() - ref).abs().max().item()
+            assert err <= tol * max(1.0, ref.abs().max().item()) * 4, (M, N, dt, err)
+
+
 def test_norm_and_attention_fwd_bwd():
     from tools import gpu_check_ops
     assert gpu_check_ops.main() == 0

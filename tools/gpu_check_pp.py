@@ -7,6 +7,7 @@ from speechmix_amd import ops
 from speechmix_amd.ops import ACT_GELU, view
 dev = torch.device("cuda:0")
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+notime = "notime" in sys.argv
 
 
 def bench(fn, n=10):
@@ -33,6 +34,7 @@ def cmp(name, got, ref, tol=2e-2):
 def main():
     torch.manual_seed(0)
     ok = True
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     shapes = [(300, 200, 136), (15968, 768, 768), (7968, 3072, 768), (15968, 768, 3072), (1000, 512, 1536), (4096, 2304, 768)]
     if quick:
         shapes = shapes[:3]
@@ -90,6 +92,8 @@ def main():
             ops.gemm(A, B, c, M, N, K, ops.BF16, cv=view(G * N), nbatch=G, batch_a=M * K, batch_b=N * K, batch_c=N, tr_mode=t)
         ok &= cmp(f"batched tr{tr}", c2, c1)
     print("ALL OK" if ok else "SOME FAILED", flush=True)
+    if "notime" in sys.argv:
+        return 0 if ok else 1
 
     # timings
     for (M, N, K) in [(15968, 3072, 768), (15968, 768, 3072), (15968, 2304, 768), (15968, 768, 768), (511968, 512, 1536),
