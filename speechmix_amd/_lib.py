@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported BEFORE the shared object: one HIP runtime per process - torch's)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspeechmix_hip.so")
+LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "libspeechmix_hip.so")     # SMX_LIB: A/B builds (tools/lab)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -35,7 +35,8 @@
 #define PP_BN 256
 #define PP_UNIT 16384
 #define PP_STAGE (4 * PP_UNIT)               // AH0 AH1 BH0 BH1
-#define PP_LDS_BYTES (2 * PP_STAGE)
+#define PP_BIAS_OFF (2 * PP_STAGE)          // 2 x 256 floats: the bias slice of the current / next work item
+#define PP_LDS_BYTES (2 * PP_STAGE + 2048)
 #define PP_GROUP 4
 #define PP_OOB 0x80000000u                   // = num_records of the operand descriptors: any offset >= it reads zeros
 
@@ -66,6 +67,12 @@ __device__ __forceinline__ const SmxGemmParams& pp_kernarg() {
     auto k = __builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(k));
     return *(const SmxGemmParams*)k;
+}
+
+// 4 B per lane: LDS[m0 + lane * 4] = mem[rsrc.base + voff]  (zeros beyond num_records)
+__device__ __forceinline__ void pp_dma4(pp_rsrc_t rsrc, unsigned voff, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %0, 0 offen lds"
+                 :: "s"(rsrc), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory");
 }
 
 struct PPItem {
@@ -420,23 +427,24 @@ __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
 }
 
 template <int EPI>
-__device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, int nw0, long long zc, long long zbias,
-                                                 long long ze, int lane) {
+__device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, int nw0, int n0, const char* bias_lds,
+                                                 long long zc, long long ze, int lane) {
     const SmxGemmParams& p = pp_kernarg();
     const int i16 = lane & 15, g = lane >> 4;
     const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
+    // bias: the item's 256-column slice was put into LDS by an LDS-DMA issued when the item started (zeros beyond N)
     float bs[2][8];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-        const int n = nl + ch * 32;
-        if (p.bias && n < p.N) {
-            load8(p.bias + zbias + n, bs[ch]);
+        if (p.bias) {
+            const float* b = reinterpret_cast<const float*>(bias_lds) + (nl - n0) + ch * 32;
+            const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
+            bs[ch][0] = lo.x; bs[ch][1] = lo.y; bs[ch][2] = lo.z; bs[ch][3] = lo.w;
+            bs[ch][4] = hi.x; bs[ch][5] = hi.y; bs[ch][6] = hi.z; bs[ch][7] = hi.w;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bs[ch][e] = 0.f;
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bs[ch][e]));      // consumed here (see pp_epilogue)
     }
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
         for (int a = 0; a < 4; ++a) for (int k = 0; k < 2; ++k) fa[a][k] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
         for (int a = 0; a < 2; ++a) for (int k = 0; k < 2; ++k) fb0[a][k] = fb1[a][k] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
     }
-    int seq = 0;
+    int seq = 0, items = 0;
     bool drained = false;
     // the launcher sets bit 7 of tr_mode when the parameters fit this instantiation's epilogue class
     const bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
@@ -587,6 +595,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        ++items;
+        if (fast_epi && wr == 0) {          // bias slice of this item -> LDS, behind everything already in flight (the last
+            const SmxGemmParams& pk = pp_kernarg();      // phase's drain retires it; an extra older operation only makes
+            if (pk.bias) {                                // the counted waits stricter)
+                pp_rsrc_t br = pp_make_rsrc(pk.bias + it.zbias + it.n0);
+                br[2] = max(pk.N - it.n0, 0) * 4;
+                pp_dma4(br, (unsigned)(wc * 64 + lane) * 4u, is.lds0 + PP_BIAS_OFF + (items & 1) * 1024 + wc * 256);
+            }
+        }
         for (int t = 0; t < it.nk; ++t) {
             const char* cur = smem + (seq & 1) * PP_STAGE;
             const int w0 = (t == 0 && drained) ? 2 : 0;
@@ -603,7 +620,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
             for (int a = 0; a < 8; ++a) for (int j = 0; j < 4; ++j) sink += acc[a][j][0] + acc[a][j][1] + acc[a][j][2] + acc[a][j][3];
             if (sink == 1234.5f) reinterpret_cast<float*>(p.C)[tid] = sink;
         } else if (fast_epi) {
-            pp_epilogue_fast<EPI>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane);
+            pp_epilogue_fast<EPI>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
+                                  it.ze, lane);
         } else {
             pp_epilogue(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane);
         }
