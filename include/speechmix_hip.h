@@ -140,6 +140,20 @@ typedef struct SmxOptParams {
 int smx_sumsq(const float* g, long long n, float* out, hipStream_t stream);
 int smx_optimizer_step(const SmxOptParams* p, hipStream_t stream);
 
+/* Adafactor over the flat buffer: the optimizer the reference trains with (ref:train.py:298 optim="adafactor" -> HF
+ * Trainer: transformers.optimization.Adafactor(lr, scale_parameter=False, relative_step=False)); replaces the per-tensor
+ * loop of TF:optimization.py Adafactor.step.  Work lists are built by the caller (speechmix_amd/ops.py AdafactorPlan). */
+typedef struct SmxAfTensor { long long off; int nb, R, C, row_off, col_off, rm_off, factored, _pad; } SmxAfTensor;
+typedef struct SmxAfTile { int tensor, b, r0, nr, c0, nc, full_rows, full_cols; } SmxAfTile;
+typedef struct SmxAfSeg { int tensor, b; } SmxAfSeg;
+typedef struct SmxAfParams {
+    float* p; const float* g; void* shadow; const SmxAfTensor* tensors; const SmxAfTile* tiles; const SmxAfSeg* segs;
+    float *row, *col, *racc, *cacc, *rmean, *usq; const float* beta2t; const float* gnorm_sq;
+    long long racc_n, cacc_n; int ntensors, ntiles, nsegs;
+    float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
+} SmxAfParams;
+int smx_adafactor_step(const SmxAfParams* p, hipStream_t stream);
+
 /* ABI self-description */
 int smx_sizeof_SmxGemmParams(void);
 int smx_sizeof_SmxNormParams(void);
@@ -149,6 +163,9 @@ int smx_sizeof_SmxConv0Params(void);
 int smx_sizeof_SmxCEParams(void);
 int smx_sizeof_SmxOptParams(void);
 int smx_sizeof_SmxWsumParams(void);
+int smx_sizeof_SmxAfParams(void);
+int smx_sizeof_SmxAfTensor(void);
+int smx_sizeof_SmxAfTile(void);
 
 #ifdef __cplusplus
 }

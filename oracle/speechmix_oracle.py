@@ -480,3 +480,36 @@ def speechmix_self_losses(sd, lm_cfg: dict, inputs_embeds: Tensor, text_input_id
     ce = cross_entropy(z_s, labels)
     return {"ce": ce, "kld": kld, "mse": mse, "loss": kld + ce + mse, "raw_logits": z_s,
             "logits": z_s.argmax(-1)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Adafactor as the reference's Trainer runs it (ref:train.py:298 optim="adafactor"; TF:trainer.py get_optimizer_cls_and_kwargs:
+# Adafactor with scale_parameter=False, relative_step=False; TF:optimization.py Adafactor.step / _approx_sq_grad / _rms).
+# Restated on plain tensors: state = {"step", "row", "col"} (>= 2-D) or {"step", "v"} (1-D).  Pinned against the HF class in
+# tests/test_oracle_golden.py::test_adafactor_restatement_matches_hf.
+def adafactor_step(p, g, state, lr, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0):
+    """In-place update of p (fp32) with gradient g; returns the update that was subtracted."""
+    if not state:
+        state["step"] = 0
+        if g.dim() >= 2:
+            state["row"] = torch.zeros(g.shape[:-1])
+            state["col"] = torch.zeros(g.shape[:-2] + g.shape[-1:])
+        else:
+            state["v"] = torch.zeros_like(g)
+    state["step"] += 1
+    beta2t = 1.0 - math.pow(state["step"], decay_rate)
+    u = g * g + eps1
+    if g.dim() >= 2:
+        state["row"].mul_(beta2t).add_(u.mean(dim=-1), alpha=1.0 - beta2t)
+        state["col"].mul_(beta2t).add_(u.mean(dim=-2), alpha=1.0 - beta2t)
+        r = (state["row"] / state["row"].mean(dim=-1, keepdim=True)).rsqrt().unsqueeze(-1)
+        c = state["col"].unsqueeze(-2).rsqrt()
+        upd = r * c * g
+    else:
+        state["v"].mul_(beta2t).add_(u, alpha=1.0 - beta2t)
+        upd = state["v"].rsqrt() * g
+    rms = upd.norm(2) / (upd.numel() ** 0.5)
+    upd = upd / torch.clamp(rms / clip_threshold, min=1.0)
+    upd = upd * lr
+    p.sub_(upd)
+    return upd

@@ -1,0 +1,302 @@
+// Adafactor on the flat parameter buffer - the optimizer the reference trains with (ref:train.py:298 `optim="adafactor"`,
+// which HF Trainer instantiates as Adafactor(lr, scale_parameter=False, relative_step=False); TF:optimization.py
+// Adafactor.step, _approx_sq_grad, _rms).  Per tensor of shape [..., R, C] (>= 2-D: factored) or [n] (unfactored):
+//     u    = g^2 + eps1
+//     row  = beta2t row + (1 - beta2t) mean_C(u)        col = beta2t col + (1 - beta2t) mean_R(u)
+//     upd  = g * rsqrt(row / mean_R(row)) * rsqrt(col)   (1-D:  v = beta2t v + (1 - beta2t) u ; upd = g rsqrt(v))
+//     upd /= max(1, rms(upd) / clip_threshold) ;  p -= lr upd           beta2t = 1 - step^decay_rate
+// The state is two vectors per matrix instead of AdamW's two full copies (2 MB instead of 1.9 GB at config 2).
+//
+// One step = a memset + four launches over host-built work lists (no per-tensor launches: 458 tensors at config 2):
+//   stats   tiles of <= 64 rows x <= 2048 columns: row sums by wave reductions, column partials in registers, one
+//           atomic per row / column only where a tile does not cover the whole row / column range
+//   fold    one block per (tensor, leading index): the two moving averages, the row mean
+//   rms     tiles again: sum upd^2 per tensor          apply   tiles again: the update + the bf16 compute copy
+// Gradient traffic 3 x 4 B + parameters 8 B + bf16 copy 2 B = 22 B / parameter (AdamW: 30).
+#include "smx_common.h"
+
+struct SmxAfTensor {
+    long long off;        // element offset of the tensor in p / g / shadow
+    int nb, R, C;         // leading (batch) count, rows, columns; 1-D tensors: nb = 1, R = 1, C = n, factored = 0
+    int row_off, col_off; // offsets into row / col state (factored) ; vec_off = col_off for 1-D tensors (state v)
+    int rm_off;           // offset into the per-(tensor, batch) row-mean array
+    int factored;
+    int _pad;
+};
+struct SmxAfTile {
+    int tensor, b, r0, nr, c0, nc;
+    int full_rows;        // tile spans every column: row sums are final (plain store)
+    int full_cols;        // tile spans every row: column sums are final
+};
+struct SmxAfSeg { int tensor, b; };
+struct SmxAfParams {
+    float* p;
+    const float* g;
+    void* shadow;                 // bf16 copy or null
+    const SmxAfTensor* tensors;
+    const SmxAfTile* tiles;
+    const SmxAfSeg* segs;
+    float* row;                   // factored state
+    float* col;                   // factored column state; 1-D tensors keep their v here too
+    float* racc;                  // scratch, same layout as row / col / per tensor (zeroed by the launcher)
+    float* cacc;
+    float* rmean;                 // [nsegs]
+    float* usq;                   // [ntensors] sum upd^2
+    const float* beta2t;          // [ntensors] (tensors without a gradient this step: < 0 -> skipped, as HF does)
+    const float* gnorm_sq;        // device scalar for global-norm clipping or null
+    long long racc_n, cacc_n;
+    int ntensors, ntiles, nsegs;
+    float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
+};
+
+#define AF_MAXC 2048
+#define AF_ROWS 64
+
+__device__ __forceinline__ float af_gscale(const SmxAfParams& o) {
+    float s = o.grad_scale;
+    if (o.max_grad_norm > 0.f && o.gnorm_sq) {
+        const float nrm = sqrtf(*o.gnorm_sq) * o.grad_scale;
+        s *= fminf(1.f, o.max_grad_norm / (nrm + 1e-6f));
+    }
+    return s;
+}
+
+// ---- stats: u = (gs g)^2 + eps1 summed along rows and columns ------------------------------------------------------
+__global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
+    __shared__ float cpart[4][AF_MAXC];
+    const SmxAfTile tl = o.tiles[blockIdx.x];
+    const SmxAfTensor T = o.tensors[tl.tensor];
+    if (o.beta2t[tl.tensor] < 0.f) return;
+    const float gs = af_gscale(o);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* g = o.g + T.off + (long long)tl.b * T.R * T.C;
+    if (!T.factored) {               // 1-D: v updated in place, sum upd^2 on the fly
+        const float b2 = o.beta2t[tl.tensor];
+        float* v = o.col + T.col_off;
+        float s = 0.f;
+        for (int c = tl.c0 + threadIdx.x; c < tl.c0 + tl.nc; c += 256) {
+            const float gi = g[c] * gs;
+            const float vi = b2 * v[c] + (1.f - b2) * (gi * gi + o.eps1);
+            v[c] = vi;
+            const float u = gi * rsqrtf(vi);
+            s += u * u;
+        }
+        s = block_sum(s, &cpart[0][0]);
+        if (threadIdx.x == 0) atomicAdd(o.usq + tl.tensor, s);
+        return;
+    }
+    float* racc = o.racc + T.row_off + (long long)tl.b * T.R;
+    float* cacc = o.cacc + T.col_off + (long long)tl.b * T.C + tl.c0;
+    if (T.C < 64) {
+        // narrow matrices (conv kernels [Co, Ci, k]: C = k): one thread per row, column sums through LDS atomics; such
+        // a tile always covers its whole (R x C) matrix
+        float* lc = &cpart[0][0];
+        if (threadIdx.x < T.C) lc[threadIdx.x] = 0.f;
+        __syncthreads();
+        for (int r = tl.r0 + threadIdx.x; r < tl.r0 + tl.nr; r += 256) {
+            const float* gr = g + (long long)r * T.C;
+            float rs = 0.f;
+            for (int c = 0; c < T.C; ++c) {
+                const float gi = gr[c] * gs;
+                const float u = gi * gi + o.eps1;
+                rs += u;
+                atomicAdd(lc + c, u);
+            }
+            racc[r] = rs;
+        }
+        __syncthreads();
+        if (threadIdx.x < T.C) cacc[threadIdx.x] = lc[threadIdx.x];
+        return;
+    }
+    // wide: wave w takes rows r0 + w, + 4 ...; a lane takes 4 consecutive columns c0 + 4 (lane + 64 j) (16-B loads when
+    // the row length allows it)
+    constexpr int NJ = AF_MAXC / 256;
+    const bool v4 = !(T.C & 3);
+    float cs[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[j][e] = 0.f;
+    for (int r = tl.r0 + w; r < tl.r0 + tl.nr; r += 4) {
+        const float* gr = g + (long long)r * T.C + tl.c0;
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = 4 * (lane + 64 * j);
+            if (c < tl.nc) {
+                float x[4];
+                if (v4) {
+                    const float4 q = *reinterpret_cast<const float4*>(gr + c);
+                    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = c + e < tl.nc ? gr[c + e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gi = x[e] * gs;
+                    const float u = (v4 || c + e < tl.nc) ? gi * gi + o.eps1 : 0.f;
+                    rs += u;
+                    cs[j][e] += u;
+                }
+            }
+        }
+        rs = wave_sum(rs);
+        if (lane == 0) {
+            if (tl.full_rows) racc[r] = rs;
+            else atomicAdd(racc + r, rs);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cpart[w][4 * (lane + 64 * j) + e] = cs[j][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < tl.nc; c += 256) {
+        const float sum = (cpart[0][c] + cpart[1][c]) + (cpart[2][c] + cpart[3][c]);
+        if (tl.full_cols) cacc[c] = sum;
+        else atomicAdd(cacc + c, sum);
+    }
+}
+
+// ---- fold: moving averages of one (tensor, leading index), and the mean of its row state ---------------------------
+__global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
+    __shared__ float sh[16];
+    const SmxAfSeg sg = o.segs[blockIdx.x];
+    const SmxAfTensor T = o.tensors[sg.tensor];
+    const float b2 = o.beta2t[sg.tensor];
+    if (b2 < 0.f || !T.factored) return;
+    float* row = o.row + T.row_off + (long long)sg.b * T.R;
+    const float* racc = o.racc + T.row_off + (long long)sg.b * T.R;
+    float* col = o.col + T.col_off + (long long)sg.b * T.C;
+    const float* cacc = o.cacc + T.col_off + (long long)sg.b * T.C;
+    const float ic = 1.0f / (float)T.C, ir = 1.0f / (float)T.R;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < T.R; r += 256) {
+        const float v = b2 * row[r] + (1.f - b2) * (racc[r] * ic);
+        row[r] = v;
+        s += v;
+    }
+    for (int c = threadIdx.x; c < T.C; c += 256) col[c] = b2 * col[c] + (1.f - b2) * (cacc[c] * ir);
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) o.rmean[T.rm_off + sg.b] = s * ir;
+}
+
+// ---- rms / apply ---------------------------------------------------------------------------------------------------
+template <bool APPLY>
+__global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o) {
+    __shared__ float sh[16];
+    const SmxAfTile tl = o.tiles[blockIdx.x];
+    const SmxAfTensor T = o.tensors[tl.tensor];
+    if (o.beta2t[tl.tensor] < 0.f) return;
+    const float gs = af_gscale(o);
+    const long long base = T.off + (long long)tl.b * T.R * T.C;
+    const float* g = o.g + base;
+    float scale = 0.f;
+    if (APPLY) {
+        const float n = (float)T.nb * (float)T.R * (float)T.C;
+        const float rms = sqrtf(o.usq[tl.tensor] / n);
+        scale = o.lr / fmaxf(1.0f, rms / o.clip_threshold);
+    }
+    bf16_t* shd = reinterpret_cast<bf16_t*>(o.shadow);
+    if (!T.factored) {
+        if (!APPLY) return;                  // sum upd^2 was taken by the stats pass
+        const float* v = o.col + T.col_off;
+        for (int c = tl.c0 + threadIdx.x; c < tl.c0 + tl.nc; c += 256) {
+            const float pi = o.p[base + c] - scale * (g[c] * gs) * rsqrtf(v[c]);
+            o.p[base + c] = pi;
+            if (shd) shd[base + c] = f2bf(pi);
+        }
+        return;
+    }
+    const float* row = o.row + T.row_off + (long long)tl.b * T.R;
+    const float* col = o.col + T.col_off + (long long)tl.b * T.C + tl.c0;
+    const float rmean = o.rmean[T.rm_off + tl.b];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (T.C < 64) {                              // narrow: one thread per row
+        for (int r = tl.r0 + threadIdx.x; r < tl.r0 + tl.nr; r += 256) {
+            const float rf = rsqrtf(row[r] / rmean) * gs;
+            const long long ro = (long long)r * T.C;
+            for (int c = 0; c < T.C; ++c) {
+                const float u = g[ro + c] * rf * rsqrtf(col[c]);
+                if (APPLY) {
+                    const float pi = o.p[base + ro + c] - scale * u;
+                    o.p[base + ro + c] = pi;
+                    if (shd) shd[base + ro + c] = f2bf(pi);
+                } else {
+                    s += u * u;
+                }
+            }
+        }
+    } else {
+        constexpr int NJ = AF_MAXC / 256;
+        const bool v4 = !(T.C & 3);
+        float cf[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * (lane + 64 * j) + e;
+                cf[j][e] = c < tl.nc ? rsqrtf(col[c]) : 0.f;
+            }
+        for (int r = tl.r0 + w; r < tl.r0 + tl.nr; r += 4) {
+            const float rf = rsqrtf(row[r] / rmean) * gs;
+            const long long ro = (long long)r * T.C + tl.c0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = 4 * (lane + 64 * j);
+                if (c >= tl.nc) continue;
+                if (v4) {
+                    const float4 q = *reinterpret_cast<const float4*>(g + ro + c);
+                    const float u0 = q.x * rf * cf[j][0], u1 = q.y * rf * cf[j][1], u2 = q.z * rf * cf[j][2], u3 = q.w * rf * cf[j][3];
+                    if (APPLY) {
+                        float4 pv = *reinterpret_cast<float4*>(o.p + base + ro + c);
+                        pv.x -= scale * u0; pv.y -= scale * u1; pv.z -= scale * u2; pv.w -= scale * u3;
+                        *reinterpret_cast<float4*>(o.p + base + ro + c) = pv;
+                        if (shd) *reinterpret_cast<uint2*>(shd + base + ro + c) = make_uint2(pack_bf2(pv.x, pv.y), pack_bf2(pv.z, pv.w));
+                    } else {
+                        s += (u0 * u0 + u1 * u1) + (u2 * u2 + u3 * u3);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (c + e >= tl.nc) continue;
+                        const float u = g[ro + c + e] * rf * cf[j][e];
+                        if (APPLY) {
+                            const float pi = o.p[base + ro + c + e] - scale * u;
+                            o.p[base + ro + c + e] = pi;
+                            if (shd) shd[base + ro + c + e] = f2bf(pi);
+                        } else {
+                            s += u * u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!APPLY) {
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) atomicAdd(o.usq + tl.tensor, s);
+    }
+}
+
+extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
+    (void)hipGetLastError();
+    SmxAfParams o = *op;
+    if (o.ntiles <= 0 || o.ntensors <= 0) return SMX_OK;
+    if (!o.p || !o.g || !o.tensors || !o.tiles || !o.segs || !o.row || !o.col || !o.racc || !o.cacc || !o.rmean || !o.usq ||
+        !o.beta2t) return SMX_EINVAL;
+    (void)hipMemsetAsync(o.racc, 0, sizeof(float) * o.racc_n, stream);
+    (void)hipMemsetAsync(o.cacc, 0, sizeof(float) * o.cacc_n, stream);
+    (void)hipMemsetAsync(o.usq, 0, sizeof(float) * o.ntensors, stream);
+    hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
+    if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_update_kernel<false>, dim3(o.ntiles), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_update_kernel<true>, dim3(o.ntiles), dim3(256), 0, stream, o);
+    SMX_CHECK_LAUNCH();
+}
+
+extern "C" int smx_sizeof_SmxAfParams(void) { return (int)sizeof(SmxAfParams); }
+extern "C" int smx_sizeof_SmxAfTensor(void) { return (int)sizeof(SmxAfTensor); }
+extern "C" int smx_sizeof_SmxAfTile(void) { return (int)sizeof(SmxAfTile); }

@@ -45,6 +45,7 @@ class Engine:
         self.downloop = int(math.log(down_scale, 2)) if down_scale > 1 else 0
         self.ep, self.lp = enc_prefix, lm_prefix
         self._persist: Dict[str, torch.Tensor] = {}
+        self.last_dropped: List[int] = []
         self._wgrad_pick: Dict[tuple, int] = {}     # tuned (kernel, K split) choice per weight-gradient shape
         self.saved = None
         rank = int(os.environ.get("RANK", "0"))         # independent draws per data-parallel rank
@@ -694,6 +695,7 @@ class Engine:
             x, sv["final_ln"] = self.ln_fwd(x, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps)
             hidden[-1] = x
         sv["hidden"] = hidden
+        self.last_dropped = [i for i, l in enumerate(sv["layers"]) if l is None]       # LayerDrop: no gradient this step
         return x, sv
 
     def speech_bwd(self, dx, sv, ws=None):

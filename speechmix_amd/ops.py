@@ -396,6 +396,80 @@ def optimizer_step(p, g, m, v, shadow, gnorm_sq, n, lr, kind="adamw", beta1=0.9,
     L.check(L.lib().smx_optimizer_step(C.byref(o), _stream()), "smx_optimizer_step")
 
 
+class AdafactorPlan:
+    """Host-built work lists + device state for smx_adafactor_step over a set of tensors living in one flat buffer.
+    tensors: [(element offset, shape)] in the flat p / g buffers.  (TF:optimization.py Adafactor: factored second
+    moments for >= 2-D tensors over their last two dims, unfactored for 1-D.)"""
+    ROWS_MIN, TILE_ELEMS, MAXC, VEC_TILE = 64, 8192, 2048, 8192
+
+    def __init__(self, tensors, device):
+        import numpy as np
+        self.n = len(tensors)
+        tt = np.zeros(self.n, dtype=np.dtype([("off", "<i8"), ("nb", "<i4"), ("R", "<i4"), ("C", "<i4"), ("row_off", "<i4"),
+                                               ("col_off", "<i4"), ("rm_off", "<i4"), ("factored", "<i4"), ("_pad", "<i4")]))
+        tiles, segs = [], []
+        row_n = col_n = rm_n = 0
+        for t, (off, shape) in enumerate(tensors):
+            numel = 1
+            for d in shape:
+                numel *= d
+            if len(shape) >= 2:
+                R, Cn = shape[-2], shape[-1]
+                nb = numel // (R * Cn)
+                tt[t] = (off, nb, R, Cn, row_n, col_n, rm_n, 1, 0)
+                if Cn < 64:
+                    tr = R                                   # narrow (conv kernels): the kernel's thread-per-row path
+                else:                                        # tall matrices: taller tiles, fewer column atomics per address
+                    tr = min(R, max(self.ROWS_MIN, self.TILE_ELEMS // Cn, (R + 511) // 512))
+                for b in range(nb):
+                    segs.append((t, b))
+                    for r0 in range(0, R, tr):
+                        for c0 in range(0, Cn, self.MAXC):
+                            tiles.append((t, b, r0, min(tr, R - r0), c0, min(self.MAXC, Cn - c0), int(Cn <= self.MAXC),
+                                          int(tr >= R)))
+                row_n += nb * R
+                col_n += nb * Cn
+                rm_n += nb
+            else:
+                tt[t] = (off, 1, 1, numel, 0, col_n, 0, 0, 0)
+                for c0 in range(0, numel, self.VEC_TILE):
+                    tiles.append((t, 0, 0, 1, c0, min(self.VEC_TILE, numel - c0), 1, 1))
+                col_n += numel
+        self.ntiles, self.nsegs = len(tiles), len(segs)
+        self.row_n, self.col_n = max(row_n, 1), max(col_n, 1)
+        dev = device
+        self.tensors = torch.from_numpy(tt.view(np.uint8).copy()).to(dev)
+        self.tiles = torch.tensor(tiles if tiles else [[0] * 8], dtype=torch.int32, device=dev)
+        self.segs = torch.tensor(segs if segs else [[0, 0]], dtype=torch.int32, device=dev)
+        self.row = torch.zeros(self.row_n, dtype=torch.float32, device=dev)
+        self.col = torch.zeros(self.col_n, dtype=torch.float32, device=dev)
+        self.racc = torch.empty(self.row_n, dtype=torch.float32, device=dev)
+        self.cacc = torch.empty(self.col_n, dtype=torch.float32, device=dev)
+        self.rmean = torch.zeros(max(rm_n, 1), dtype=torch.float32, device=dev)
+        self.usq = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.beta2t = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.steps = np.zeros(self.n, dtype=np.int64)          # per-tensor step counts (HF keeps state["step"] per tensor)
+        self._np = np
+
+    def step(self, p, g, shadow, gnorm_sq, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
+             max_grad_norm=0.0):
+        """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched)."""
+        np = self._np
+        act = np.ones(self.n, dtype=bool) if active is None else np.asarray(active, dtype=bool)
+        self.steps[act] += 1
+        b2 = np.where(act, 1.0 - np.power(np.maximum(self.steps, 1).astype(np.float64), decay_rate), -1.0).astype(np.float32)
+        self.beta2t.copy_(torch.from_numpy(b2), non_blocking=True)
+        o = L.AfParams()
+        o.p, o.g, o.shadow = _ptr(p), _ptr(g), _ptr(shadow)
+        o.tensors, o.tiles, o.segs = _ptr(self.tensors), _ptr(self.tiles), _ptr(self.segs)
+        o.row, o.col, o.racc, o.cacc, o.rmean, o.usq = _ptr(self.row), _ptr(self.col), _ptr(self.racc), _ptr(self.cacc), \
+            _ptr(self.rmean), _ptr(self.usq)
+        o.beta2t, o.gnorm_sq = _ptr(self.beta2t), _ptr(gnorm_sq)
+        o.racc_n, o.cacc_n, o.ntensors, o.ntiles, o.nsegs = self.row_n, self.col_n, self.n, self.ntiles, self.nsegs
+        o.lr, o.eps1, o.clip_threshold, o.grad_scale, o.max_grad_norm = lr, eps1, clip_threshold, grad_scale, max_grad_norm
+        L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
+
+
 def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):
     L.check(L.lib().smx_act_bwd(C.c_void_p(_ptr(dy)), C.c_void_p(_ptr(pre)), C.c_void_p(_ptr(dx)), M, N,
                                 C.byref(out_view), act, dtype, _stream()), "smx_act_bwd")

@@ -43,11 +43,27 @@ class StepRunner:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         n = self.store.total
         dev = self.store.device
-        self.m = torch.zeros(n, dtype=torch.float32, device=dev) if (optimizer == "adamw" or momentum > 0) else None
+        if optimizer not in ("adamw", "sgd", "adafactor"):
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev) if (optimizer == "adamw" or (optimizer == "sgd" and momentum > 0)) \
+            else None
         self.v = torch.zeros(n, dtype=torch.float32, device=dev) if optimizer == "adamw" else None
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
         self.ranges = trainable_ranges(self.store)
+        self.af = None
+        if optimizer == "adafactor":
+            # the reference's optimizer (ref:train.py:298 -> HF Trainer: Adafactor(lr, scale_parameter=False,
+            # relative_step=False)); one fused multi-tensor step over the flat buffer (csrc/adafactor.hip)
+            self.af_names = [nm for nm, _ in sorted(self.store.offsets.items(), key=lambda kv: kv[1][0])
+                             if self.store.requires_grad(nm)]
+            self.af = ops.AdafactorPlan([(self.store.offsets[nm][0], self.store.offsets[nm][2]) for nm in self.af_names], dev)
+            ep = self.engine.ep
+            self._af_layer = [-1] * len(self.af_names)             # encoder layer index of each tensor (LayerDrop bookkeeping)
+            for i, nm in enumerate(self.af_names):
+                pre = ep + "encoder.layers."
+                if nm.startswith(pre):
+                    self._af_layer[i] = int(nm[len(pre):].split(".", 1)[0])
         self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, model.num_speech_encoder_layers),
                                    force_comm=force_comm)
         self.engine.stage_cb = self.reducer.stage_done
@@ -76,6 +92,15 @@ class StepRunner:
         if clip > 0:
             ops.sumsq(st.grad, st.total, self.gnorm_sq)
         sh = None if st.shadow is st.master else st.shadow
+        if self.af is not None:
+            active = None
+            if self.world == 1 and eng.last_dropped:      # HF skips parameters without a gradient (a dropped layer's);
+                dropped = set(eng.last_dropped)           # across ranks the all-reduce gives every tensor a gradient
+                active = [l not in dropped for l in self._af_layer]
+            self.af.step(st.master, st.grad, sh, self.gnorm_sq if clip > 0 else None, self.lr, active=active,
+                         grad_scale=inv_world, max_grad_norm=clip)
+            st.mark_shadow_fresh()
+            return out["loss"]
         for a, b in self.ranges:
             ops.optimizer_step(st.master[a:b], st.grad[a:b], self.m[a:b] if self.m is not None else None,
                                self.v[a:b] if self.v is not None else None, sh[a:b] if sh is not None else None,

@@ -40,6 +40,53 @@ def test_colsum_two_stage_and_atomic():
             assert err <= tol * max(1.0, ref.abs().max().item()) * 4, (M, N, dt, err)
 
 
+def test_adafactor_flat_step_matches_oracle():
+    """smx_adafactor_step over a flat buffer of model-shaped tensors vs the oracle restatement of HF Adafactor (pinned to
+    the HF class in tests/test_oracle_golden.py): three steps, one tensor without a gradient in step 2, global-norm
+    clipping on, bf16 compute copy refreshed."""
+    import torch
+    from oracle import speechmix_oracle as O
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(768, 3072), (512, 512, 3), (3072,), (1, 5027), (768, 48, 128), (1, 1, 128), (512, 1, 10), (100, 4100), (768,)]
+    offs, total = [], 0
+    for s in shapes:
+        offs.append(total)
+        n = 1
+        for d in s:
+            n *= d
+        total += (n + 63) // 64 * 64
+    p = torch.randn(total) * 0.3
+    ref = [p[o:o + torch.Size(s).numel()].view(s).clone() for o, s in zip(offs, shapes)]
+    states = [dict() for _ in shapes]
+    pd = p.to(dev)
+    shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+    plan = ops.AdafactorPlan(list(zip(offs, shapes)), dev)
+    gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+    for step in range(3):
+        g = torch.zeros(total)
+        for i, (o, s) in enumerate(zip(offs, shapes)):
+            g[o:o + torch.Size(s).numel()] = torch.randn(torch.Size(s).numel()) * (5.0 if (i == 2 and step == 1) else 0.05)
+        active = [not (step == 1 and i == 4) for i in range(len(shapes))]
+        gd = g.to(dev)
+        ops.sumsq(gd, total, gnorm)
+        clip = min(1.0, 1.0 / (g.norm().item() * 0.5 + 1e-6))
+        plan.step(pd, gd, shadow, gnorm, 5e-4, active=active, grad_scale=0.5, max_grad_norm=1.0)
+        for i, (o, s) in enumerate(zip(offs, shapes)):
+            if active[i]:
+                O.adafactor_step(ref[i], g[o:o + torch.Size(s).numel()].view(s) * (0.5 * clip), states[i], lr=5e-4)
+        got = pd.cpu()
+        for i, (o, s) in enumerate(zip(offs, shapes)):
+            a, b = got[o:o + torch.Size(s).numel()].view(s), ref[i]
+            err = (a - b).abs().max().item()
+            assert err < 2e-6 + 2e-5 * 5e-4, (step, s, err)
+    sh = shadow.float().cpu()
+    for i, (o, s) in enumerate(zip(offs, shapes)):
+        n = torch.Size(s).numel()
+        assert torch.equal(sh[o:o + n], got[o:o + n].bfloat16().float())
+
+
 def test_norm_and_attention_fwd_bwd():
     from tools import gpu_check_ops
     assert gpu_check_ops.main() == 0

@@ -134,3 +134,17 @@ def test_structure_invariants_recorded():
         before, after = s[f"frames@{ds}"]
         assert round(before / after) == ds
         assert O.conv_out_len(8000, [10, 3, 3, 3, 3, 2, 2], [5, 2, 2, 2, 2, 2, 2]) == before
+
+
+def test_adafactor_restatement_matches_hf():
+    """oracle.adafactor_step vs transformers.optimization.Adafactor as HF Trainer configures it for optim="adafactor"
+    (ref:train.py:298): three steps on five tensor shapes (tests/golden/make_adafactor_golden.py)."""
+    z = np.load(f"{GOLDEN}/adafactor.npz")
+    names = sorted({k.split("::")[1] for k in z.files})
+    assert len(names) == 5
+    for nm in names:
+        p = torch.from_numpy(z[f"p0::{nm}"]).clone()
+        st = {}
+        for step in range(3):
+            O.adafactor_step(p, torch.from_numpy(z[f"g{step}::{nm}"]), st, lr=5e-4)
+            _close(p, torch.from_numpy(z[f"p{step + 1}::{nm}"]), atol=1e-6, rtol=1e-6, what=f"adafactor {nm} step {step}")
