@@ -22,6 +22,7 @@ for k in f:
     write = sum(w[k]) / nw if nw else 0.0
     out[k] = {"launches": nf, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
               "hbm_bytes_per_launch": round(fetch + write)}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE -- python3 bench.py --no-cpu-baseline --no-profile --eval-mode "
-                     "--steps 2 --warmup 1 (all 3 steps averaged); FETCH_SIZE doubled (gfx950 correction), KB -> bytes",
+json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
+                     "--warmup 2 --no-cpu-baseline --no-profile (train mode; all launches of the run averaged, tuning launches "
+                     "included); FETCH_SIZE doubled (gfx950 correction), KB -> bytes",
            "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]))}, sys.stdout, indent=1)
