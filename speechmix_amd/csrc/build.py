@@ -14,6 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), "libspeechmix_hip.so")
 OBJ = os.path.join(HERE, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+if os.environ.get("SMX_DEFS"):        # extra -D switches for A/B builds, comma separated
+    FLAGS += ["-D" + d for d in os.environ["SMX_DEFS"].split(",")]
 if os.environ.get("SMX_PP_LAB"):      # ablation variants of the ping-pong GEMM (tools/gpu_pp_ksweep.py)
     FLAGS.append("-DSMX_PP_LAB")
 

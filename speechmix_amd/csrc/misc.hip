@@ -244,22 +244,30 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
     if (w == 0 && c < N) out[c] += alpha * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 // out[n] += alpha * sum_m x[m, n].  ws: >= smx_colsum_ws_floats(M, N) floats of scratch, or null (atomic single-stage form).
-extern "C" long long smx_colsum_ws_floats(int M, int N) {
+#ifndef SMX_COLSUM_MINM
+#define SMX_COLSUM_MINM 4096
+#endif
+static int colsum_slices(int M, int N) {
     const int gx = (N + 511) / 512;
-    int gy = max(1, 1024 / gx);
+#ifdef SMX_COLSUM_GY
+    int gy = SMX_COLSUM_GY;
+#else
+    // measured (tools/gpu_colsum_bench.py): 10^5-row inputs want ~4 workgroups per CU; at the encoder's 16 k rows more
+    // than 64-128 row slices only make the fold pass longer
+    int gy = M >= 131072 ? max(1, 1024 / gx) : (gx <= 2 ? 128 : 64);
+#endif
     if (gy > (M + 31) / 32) gy = (M + 31) / 32;
-    return (long long)gy * ((N + 7) / 8 * 8);
+    return gy;
 }
+extern "C" long long smx_colsum_ws_floats(int M, int N) { return (long long)colsum_slices(M, N) * ((N + 7) / 8 * 8); }
 extern "C" int smx_colsum_ws(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, float* ws,
                              hipStream_t stream) {
-    // measured (tools/gpu_colsum_bench.py): the two-stage form wins for the CNN's 10^5-row inputs only (151 vs 187 us at
-    // 511968 x 512); at the encoder's 16 k rows the second launch costs more than the atomics it removes
-    if (!ws || (N & 7) || M < 131072) return smx_colsum(x, out, M, N, ld, alpha, dtype, stream);
+    // short inputs: the second launch costs more than the atomics it removes
+    if (!ws || (N & 7) || M < SMX_COLSUM_MINM) return smx_colsum(x, out, M, N, ld, alpha, dtype, stream);
     (void)hipGetLastError();
     if (M <= 0 || N <= 0 || (ld & 7)) return SMX_EINVAL;
     const int gx = (N + 511) / 512, Np = (N + 7) / 8 * 8;
-    int gy = max(1, 1024 / gx);                   // ~4 workgroups per CU
-    if (gy > (M + 31) / 32) gy = (M + 31) / 32;
+    const int gy = colsum_slices(M, N);
     dim3 grid(gx, gy);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, ws, M, N, ld, Np);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, ws, M, N, ld, Np);
