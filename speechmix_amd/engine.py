@@ -901,6 +901,130 @@ class Engine:
         sv["logits"], sv["V"], sv["Vp"] = logits, V, Vp
         return logits, enc, sv
 
+    # ------------------------------------------------------------------ greedy decoding with a KV cache (inference)
+    def lm_encode(self, inputs_embeds, input_ids, B, S):
+        """Text-encoder half of lm_fwd in eval mode, without saved state.  -> encoder output [B*S, d]."""
+        lc, lp = self.lc, self.lp
+        d = lc.d_model
+        t5 = lc.model_type == "t5"
+        if t5:
+            raise NotImplementedError("cached greedy decoding: BART / mBART decoders only (T5's relative bias is not wired)")
+        pre_ln = lc.model_type == "mbart"
+        act = _act_id(lc.activation_function)
+        emb_name = lp + "model.shared.weight"
+        escale = math.sqrt(d) if lc.scale_embedding else 1.0
+        if inputs_embeds is None:
+            x = self.new(B * S, d)
+            ops.embed_fwd(input_ids, self.W(emb_name), x, B * S, d, escale, self.dt)
+        else:
+            x = inputs_embeds
+        eps = 1e-5
+        pe = lp + "model.encoder."
+        h, _ = self.ln_fwd(x, pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", B * S, d, eps,
+                           pos=self.W(pe + "embed_positions.weight"), pos_period=S, pos_offset=2, want_sum=True)
+        for i in range(lc.encoder_layers):
+            h, _ = self.layer_fwd(h, B, S, d, lc.encoder_attention_heads, lc.encoder_ffn_dim, self._bart_layer_names("encoder", i),
+                                  pre_ln, act, eps)
+        if pre_ln:
+            h, _ = self.ln_fwd(h, pe + "layer_norm.weight", pe + "layer_norm.bias", B * S, d, eps)
+        return h
+
+    def greedy_decode(self, enc, B, S, max_new_tokens, start_id, eos_id, pad_id, forced=None, keep_logits=None):
+        """Greedy decoding against a fixed encoder output with per-layer K/V caches: the cross-attention K/V are
+        projected once, every step projects ONE new token per clip (its K/V land in the cache through the GEMM's output
+        view), attends over the cached prefix and takes the arg-max of the LM head.  Replaces the reference's loops that
+        re-run the whole decoder - and in the notebook the whole speech encoder - per token (ref:train.py:18-34,
+        ref:eval.ipynb cell 6).  Returns int64 [B, n] generated ids (without the start token; rows that hit eos are padded
+        with pad_id after it) and the number of steps run.  forced [B, n] int64: feed these tokens instead of the arg-max
+        (scoring a given continuation through the cached path); keep_logits: list that receives each step's [B, V] logits."""
+        lc, lp = self.lc, self.lp
+        if lc.model_type == "t5":
+            raise NotImplementedError("cached greedy decoding: BART / mBART decoders only")
+        d, H, F = lc.d_model, lc.decoder_attention_heads, lc.decoder_ffn_dim
+        pre_ln = lc.model_type == "mbart"
+        act = _act_id(lc.activation_function)
+        eps, scale = 1e-5, (d // H) ** -0.5
+        emb_name = lp + "model.shared.weight"
+        escale = math.sqrt(d) if lc.scale_embedding else 1.0
+        pd = lp + "model.decoder."
+        Lmax = max_new_tokens
+        names = [self._bart_layer_names("decoder", i) for i in range(lc.decoder_layers)]
+        # cross-attention K/V of every layer, once
+        xkv = []
+        for nm in names:
+            kn, vn = nm["xattn"]["k"], nm["xattn"]["v"]
+            xkv.append(self.lin(enc, self.st.cat([kn[0], vn[0]]), self.st.cat([kn[1], vn[1]], "p32"), B * S, 2 * d, d))
+        cache = [self.zeros(B, Lmax, 2 * d) for _ in names]            # self-attention K | V per position
+        V = lc.vocab_size
+        Vp = (V + 7) // 8 * 8
+        head = lp + "lm_head.weight" if self.has(lp + "lm_head.weight") else emb_name
+        flb = self.st.module.get_buffer(lp + "final_logits_bias").view(-1)
+        logits = self.new(B, Vp, dt=torch.float32)
+        tok = torch.full((B,), start_id, dtype=torch.int64, device=self.dev)
+        nxt = torch.empty(B, dtype=torch.int64, device=self.dev)
+        done = torch.zeros(B, dtype=torch.bool, device=self.dev)
+        out = torch.full((B, Lmax), pad_id, dtype=torch.int64, device=self.dev)
+        lse = self.new(B * H, dt=torch.float32)
+        steps = 0
+        for t in range(Lmax):
+            y = self.new(B, d)
+            ops.embed_fwd(tok, self.W(emb_name), y, B, d, escale, self.dt)
+            y, _ = self.ln_fwd(y, pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", B, d, eps,
+                               pos=self.W(pd + "embed_positions.weight"), pos_period=1, pos_offset=2 + t, want_sum=True)
+            for li, nm in enumerate(names):
+                def attend(xq, wq, bq, kbuf, k_bs, k_ld, Tk):
+                    q = self.lin(xq, self.W(wq), self.P(bq), B, d, d)
+                    desc = ops.AttnDesc(B, H, 1, Tk, d // H, False, scale)
+                    desc.set("Q", q, 0, d, d)
+                    desc.set("K", kbuf, 0, k_bs, k_ld)
+                    desc.set("V", kbuf, d, k_bs, k_ld)
+                    o = self.new(B, d)
+                    desc.set("O", o, 0, d, d)
+                    ops.attention_fwd(desc, lse, self.dt)
+                    return o
+                a = nm["attn"]
+                x0 = y
+                xin = self.ln_fwd(x0, nm["ln1"][0], nm["ln1"][1], B, d, eps)[0] if pre_ln else x0
+                # this token's K | V straight into the cache row t of every clip
+                self.lin(xin, self.st.cat([a["k"][0], a["v"][0]]), self.st.cat([a["k"][1], a["v"][1]], "p32"), B, 2 * d, d,
+                         y=cache[li], cv=view(Lmax * 2 * d, 0, 0, t * 2 * d))
+                o = attend(xin, a["q"][0], a["q"][1], cache[li], Lmax * 2 * d, 2 * d, t + 1)
+                s1 = self.lin(o, self.W(a["o"][0]), self._b(a["o"][1]), B, d, d, resid=x0)
+                if pre_ln:
+                    h = s1
+                    xin2 = self.ln_fwd(h, nm["lnx"][0], nm["lnx"][1], B, d, eps)[0]
+                else:
+                    h = self.ln_fwd(s1, nm["ln1"][0], nm["ln1"][1], B, d, eps)[0]
+                    xin2 = h
+                xa = nm["xattn"]
+                o2 = attend(xin2, xa["q"][0], xa["q"][1], xkv[li], S * 2 * d, 2 * d, S)
+                s2 = self.lin(o2, self.W(xa["o"][0]), self._b(xa["o"][1]), B, d, d, resid=h)
+                if pre_ln:
+                    n2 = self.ln_fwd(s2, nm["ln2"][0], nm["ln2"][1], B, d, eps)[0]
+                    y, _ = self._ffn_fwd(n2, B, d, F, nm["fc1"], nm["fc2"], act, s2)
+                else:
+                    h2 = self.ln_fwd(s2, nm["lnx"][0], nm["lnx"][1], B, d, eps)[0]
+                    s3, _ = self._ffn_fwd(h2, B, d, F, nm["fc1"], nm["fc2"], act, h2)
+                    y = self.ln_fwd(s3, nm["ln2"][0], nm["ln2"][1], B, d, eps)[0]
+            if pre_ln:
+                y = self.ln_fwd(y, pd + "layer_norm.weight", pd + "layer_norm.bias", B, d, eps)[0]
+            ops.gemm(y, self.W(head), logits, B, V, d, self.dt, cv=view(Vp), bias=flb, out_f32=True)
+            ops.cross_entropy(logits, None, None, nxt, None, B, V, Vp, Vp, self.dt)
+            steps += 1
+            if keep_logits is not None:
+                keep_logits.append(logits[:, :V].clone())
+            if forced is not None:
+                out[:, t] = nxt
+                tok = forced[:, t].contiguous()
+                continue
+            # bookkeeping on a handful of ints (plumbing): finished rows keep emitting pad
+            out[:, t] = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+            done = done | (nxt == eos_id)
+            tok = torch.where(done, torch.full_like(nxt, eos_id), nxt)
+            if bool(done.all()):
+                break
+        return out[:, :steps], steps
+
     # ------------------------------------------------------------------ SpeechMixSelf hidden-state matching
     def self_mse(self, enc_s, enc_t, B, S, Lt, want_grad=True):
         """ref:speechmix/model.py:247-255.  enc_s [B*S,d] speech-side LM-encoder output, enc_t [B*Lt,d] text side.

@@ -317,6 +317,53 @@ class SpeechMixEED(nn.Module):
             out["loss"] = loss.view(())
         return out
 
+    # ------------------------------------------------------------------ greedy decoding
+    def _greedy(self, enc, B, S, max_length):
+        lc = self.decoder_model.config
+        n = int(max_length if max_length is not None else getattr(lc, "max_length", 20) or 20)
+        ids, _ = self.engine.greedy_decode(enc, B, S, n, lc.decoder_start_token_id, lc.eos_token_id, lc.pad_token_id)
+        rows = []
+        for r in ids.cpu().tolist():
+            rows.append(r[:r.index(lc.eos_token_id)] if lc.eos_token_id in r else r)
+        return rows
+
+    @torch.no_grad()
+    def generate(self, input_values, max_length=None):
+        """Greedy transcription: speech encoder, adapters and LM text encoder run ONCE, then a KV-cached decoder step per
+        token (the reference's notebook loop re-runs the whole model per token, ref:eval.ipynb cell 6).  Returns one list of
+        generated token ids per clip (no start token, cut before eos)."""
+        self._need_engine()
+        eng = self.engine
+        self.store.refresh_shadow()
+        wave = self._prep_wave(input_values)
+        B, N = wave.shape
+        x, ssv = eng.speech_fwd(wave, B, N, False)
+        T = ssv["T"]
+        if self.weighted_sum:
+            hidden = ssv["hidden"]
+            sw = eng.new(len(hidden), dt=torch.float32)
+            xin = eng.new(B * T, eng.ec.hidden_size)
+            ops.weighted_sum_fwd(hidden, eng.P("weights_sum"), xin, sw, B * T * eng.ec.hidden_size, eng.dt)
+            x = xin
+        e, S, _ = eng.bridge_fwd(x, B, T)
+        enc = eng.lm_encode(e, None, B, S)
+        return self._greedy(enc, B, S, max_length)
+
+    @torch.no_grad()
+    def generate_from_text(self, input_ids, max_length=None):
+        """LM-only greedy decoding of token ids [B, S] - what `create_self_decoder_input` loops over to make labels
+        (ref:train.py:18-34: decoder_length = max(config.max_length, len(input)); stop at eos)."""
+        self._need_engine()
+        self.store.refresh_shadow()
+        ids = torch.as_tensor(input_ids).to(self.device)
+        if ids.dim() == 1:
+            ids = ids[None]
+        B, S = ids.shape
+        enc = self.engine.lm_encode(None, ids.reshape(-1).contiguous(), B, S)
+        if max_length is None:
+            max_length = max(int(getattr(self.decoder_model.config, "max_length", 20) or 20), S)
+        return self._greedy(enc, B, S, max_length)
+
     def cal_loss(self, inputs_embeds=None, attention_mask=None, decoder_input_ids=None, labels=None):
         """ref:speechmix/model.py:132-137 - LM on `inputs_embeds` (no speech side, no autograd)."""
         return self._lm_only(inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids, labels=labels)
