@@ -167,3 +167,25 @@ def test_config_presets_and_errors():
         load_speech_config("no-such-model")
     with pytest.raises(ValueError):
         load_lm_config({"model_type": "gpt2"})
+
+
+def test_collator_restates_reference_padding_rules():
+    """ref:train.py:90-133: waveform padded with -100, labels padded then masked to -100, shared leading bos cut;
+    cross-checked against an HF tokenizer's own pad() when transformers is importable."""
+    import types
+    from speechmix_amd.data import DataCollatorWithPadding, DevicePrefetcher
+    tok = types.SimpleNamespace(pad_token_id=1, bos_token_id=5)
+    feats = [dict(input_values=[0.1, 0.2, 0.3], labels=[5, 9, 8, 2], text_input_ids=[5, 9, 8]),
+             dict(input_values=[0.5], labels=[5, 7, 2], text_input_ids=[5, 7])]
+    b = DataCollatorWithPadding(tok)(feats)
+    assert b["input_values"].tolist() == [[pytest.approx(0.1), pytest.approx(0.2), pytest.approx(0.3)], [0.5, -100.0, -100.0]]
+    assert b["labels"].tolist() == [[9, 8, 2], [7, 2, -100]]                       # bos column cut, pad -> -100
+    assert b["text_input_ids"].tolist() == [[5, 9, 8], [5, 7, 1]]                  # padded with pad id, not masked
+    feats[1]["labels"] = [6, 7, 2]                                                 # bos not shared by every row: kept
+    assert DataCollatorWithPadding(tok)(feats)["labels"].tolist() == [[5, 9, 8, 2], [6, 7, 2, -100]]
+    tok0 = types.SimpleNamespace(pad_token_id=1, bos_token_id=0)                   # bos id 0 is falsy: never cut (as the reference)
+    f0 = [dict(input_values=[0.0], labels=[0, 4]), dict(input_values=[0.0], labels=[0, 3])]
+    assert DataCollatorWithPadding(tok0)(f0)["labels"].tolist() == [[0, 4], [0, 3]]
+    # CPU prefetcher is a pass-through iterator
+    out = list(DevicePrefetcher([b, b], "cpu"))
+    assert len(out) == 2 and out[0]["labels"] is b["labels"]
