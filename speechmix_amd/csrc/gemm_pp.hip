@@ -140,15 +140,15 @@ __device__ __forceinline__ void pp_decode(const SmxGemmParams& p, const PPDiv& d
 // their 16-B chunks with pp_bswz so that the permuted fragment rows {8 (i>>2) + 4 j + (i & 3)} stay conflict-free.
 __device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
-template <bool RC, bool IS_A>
+template <bool RC, bool IS_A, bool VIEW>
 struct PPOperand {
     pp_rsrc_t rsrc;
     unsigned soff;          // scalar byte offset of the current K tile
     unsigned sstep;         // its increment per K tile
     unsigned voff[2][2];    // KC: [half][pass] byte offset of my (row, chunk);  RC: [0][pass] = my k-row, [1][half] = my columns
     int kc;                 // KC: first k of my chunk inside a K tile;  RC: my k-row inside a K tile (pass 0)
-    int rt[2], rb[2];       // RC through a batched view: my k-row as (row inside batch, batch), per pass
-    int rpb;                // RC: rows per batch of the view (0: plain rows)
+    int rt[1], rb[1];       // RC through a batched view (VIEW): my pass-0 k-row as (row inside batch, batch); pass 1 = +32 rows
+    int rpb;                // RC + VIEW: rows per batch of the view
 
     static __device__ __forceinline__ int grow(int h, int hr) {      // unit-local row -> tile row
         if (IS_A) return (hr >> 6) * 128 + h * 64 + (hr & 63);
@@ -173,22 +173,19 @@ struct PPOperand {
                 }
         } else {
             const int kl = wave * 4 + (lane >> 4), g16 = lane & 15;      // rc_swz(kl) is the same for both passes
-            kc = kl;
+            kc = 0;                                                      // (RC recomputes its k-row from the lane id)
             const int hc = ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int c = row0 + grow(h, hc);
                 voff[1][h] = c < nrows ? (unsigned)c * 2u : PP_OOB;
             }
-            rpb = v.rows_per_batch > 0 ? v.rows_per_batch : 0;
-            if (v.rows_per_batch > 0) {
+            rpb = VIEW ? (v.rows_per_batch > 0 ? v.rows_per_batch : 0x40000000) : 0;     // plain rows: one endless batch
+            if constexpr (VIEW) {
                 soff = 0; sstep = 0;
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int k = k0 + ps * 32 + kl;
-                    rb[ps] = pp_fdiv(k, v.rows_per_batch, rrpb);
-                    rt[ps] = k - rb[ps] * v.rows_per_batch;
-                }
+                const int k = k0 + kl;
+                rb[0] = v.rows_per_batch > 0 ? pp_fdiv(k, v.rows_per_batch, rrpb) : 0;
+                rt[0] = k - rb[0] * (v.rows_per_batch > 0 ? v.rows_per_batch : 0);
                 view_rows(v);
             } else {
                 soff = (unsigned)((long long)k0 * v.ld * 2);
@@ -199,14 +196,16 @@ struct PPOperand {
         }
     }
     __device__ __forceinline__ void view_rows(const SmxRowView& v) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-            voff[0][ps] = (unsigned)((v.off + (long long)rb[ps] * v.batch_stride + (long long)rt[ps] * v.ld) * 2);
+        int t1 = rt[0] + 32, b1 = rb[0];                       // pass 1: 32 k-rows further
+        while (t1 >= rpb) { t1 -= rpb; b1 += 1; }
+        voff[0][0] = (unsigned)((v.off + (long long)rb[0] * v.batch_stride + (long long)rt[0] * v.ld) * 2);
+        voff[0][1] = (unsigned)((v.off + (long long)b1 * v.batch_stride + (long long)t1 * v.ld) * 2);
     }
     // unit H of the K tile whose first k is k0 -> LDS at byte address lds (wave-uniform part added here)
     template <int H>
     __device__ __forceinline__ void issue(unsigned lds, int k0, int K, int wave_u) const {
         const bool tail = k0 + BK > K;                // uniform: only the last K tile of an operand pays for the selects
+        const int krow = wave_u * 4 + ((int)(threadIdx.x & 63) >> 4);       // RC: my k-row inside a pass
         if (!RC) {
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
@@ -218,29 +217,26 @@ struct PPOperand {
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {
                 unsigned vo = voff[0][ps] + voff[1][H];       // column part is PP_OOB when out of range: the sum stays >= 2^31
-                if (tail && k0 + ps * 32 + kc >= K) vo = PP_OOB;
+                if (tail && k0 + ps * 32 + krow >= K) vo = PP_OOB;
                 pp_dma16(rsrc, vo, soff, lds + (ps * 32 + wave_u * 4) * 256);
             }
         }
     }
     __device__ __forceinline__ void advance() {
         soff += sstep;
-        if (RC && rpb > 0) {
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                rt[ps] += BK;
-                while (rt[ps] >= rpb) { rt[ps] -= rpb; rb[ps] += 1; }
-            }
+        if constexpr (RC && VIEW) {
+            rt[0] += BK;
+            while (rt[0] >= rpb) { rt[0] -= rpb; rb[0] += 1; }
             view_rows(IS_A ? pp_kernarg().a : pp_kernarg().b);
         }
     }
 };
 
 // Issue side of the flat unit stream: runs six units ahead of the compute side over the same (item, K tile) sequence.
-template <bool A_RC, bool B_RC>
+template <bool A_RC, bool B_RC, bool BVIEW>
 struct PPIssue {
-    PPOperand<A_RC, true> a;
-    PPOperand<B_RC, false> b;
+    PPOperand<A_RC, true, BVIEW && A_RC> a;    // BVIEW: the (RC, RC) instantiation whose operands go through batched views
+    PPOperand<B_RC, false, BVIEW> b;
     PPDiv dv;
     int q, qstep;
     int kt, nk, k0, seq, wave_u, K;
@@ -301,9 +297,9 @@ __device__ __forceinline__ bf16x8_t pp_bfrag(const char* unit, int r32, int j, i
     return f.v;
 }
 
-template <int PH, bool A_RC, bool B_RC, int LAB>
+template <int PH, bool A_RC, bool B_RC, bool BVIEW, int LAB>
 __device__ __forceinline__ void pp_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4][2],
-                                         bf16x8_t (&fb0)[2][2], bf16x8_t (&fb1)[2][2], PPIssue<A_RC, B_RC>& is,
+                                         bf16x8_t (&fb0)[2][2], bf16x8_t (&fb1)[2][2], PPIssue<A_RC, B_RC, BVIEW>& is,
                                          const char* cur, int tid, int lane, int wr, int wc, int wmode) {
     // LAB (ablation builds only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 16 no epilogue
     // ---- load segment: register sub-tile reads + one unit of LDS-DMA, then the counted wait for the NEXT phase's unit
@@ -546,7 +542,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
     }
 }
 
-template <bool A_RC, bool B_RC, int EPI, int LAB = 0>
+template <bool A_RC, bool B_RC, int EPI, int LAB = 0, bool BVIEW = false>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -554,7 +550,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
     const int ntm = (p.M + PP_BM - 1) / PP_BM, ntn = (p.N + PP_BN - 1) / PP_BN;
     const int W = ntm * ntn * p.nbatch * p.split_k;
 
-    PPIssue<A_RC, B_RC> is;
+    PPIssue<A_RC, B_RC, BVIEW> is;
     is.dv.init(p, ntm, ntn);
     is.q = blockIdx.x; is.qstep = gridDim.x;
     is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
@@ -608,10 +604,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
             const char* cur = smem + (seq & 1) * PP_STAGE;
             const int w0 = (t == 0 && drained) ? 2 : 0;
             const int w3 = (t == it.nk - 1) ? 1 : w0;
-            pp_phase<0, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
-            pp_phase<1, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
-            pp_phase<2, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
-            pp_phase<3, A_RC, B_RC, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w3);
+            pp_phase<0, A_RC, B_RC, BVIEW, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
+            pp_phase<1, A_RC, B_RC, BVIEW, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
+            pp_phase<2, A_RC, B_RC, BVIEW, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w0);
+            pp_phase<3, A_RC, B_RC, BVIEW, LAB>(acc, fa, fb0, fb1, is, cur, tid, lane, wr, wc, w3);
             ++seq;
         }
         drained = it.nk > 0;
@@ -638,14 +634,14 @@ static int pp_epi_class(const SmxGemmParams& p) {
     return PP_EPI_LINEAR;
 }
 
-template <bool A_RC, bool B_RC, int EPI>
+template <bool A_RC, bool B_RC, int EPI, bool BVIEW = false>
 static void pp_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<A_RC, B_RC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<A_RC, B_RC, EPI, 0, BVIEW>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<A_RC, B_RC, EPI>), grid, dim3(512), PP_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<A_RC, B_RC, EPI, 0, BVIEW>), grid, dim3(512), PP_LDS_BYTES, stream, p);
 }
 
 int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
@@ -664,6 +660,8 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
     // (sizes below 2^22: the in-kernel index arithmetic divides through fp32 reciprocals)
     if (W >= (1 << 22) || p.M >= (1 << 22) || p.N >= (1 << 22) || p.K >= (1 << 22) || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
         ((p.K & 7) && !(p.a_rc && p.b_rc))) return SMX_EINVAL;
+    // rows-contiguous operands through a batched view: instantiated for the (RC, RC) layout only (conv weight gradients)
+    if (!(p.a_rc && p.b_rc) && ((p.a_rc && p.a.rows_per_batch > 0) || (p.b_rc && p.b.rows_per_batch > 0))) return SMX_EINVAL;
     dim3 grid((unsigned)(W < ncu ? W : ncu));
     const int lab = p.tr_mode >> 8;
     const int epi = pp_epi_class(p);
@@ -698,7 +696,10 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
         if (epi == PP_EPI_F32) PP_GO(false, true, PP_EPI_F32)
         PP_GO(false, true, PP_EPI_LINEAR)
     }
-    if (p.a_rc && p.b_rc) PP_GO(true, true, PP_EPI_F32)
+    if (p.a_rc && p.b_rc) {
+        if (p.b.rows_per_batch > 0 || p.a.rows_per_batch > 0) { if (epi == PP_EPI_F32) p.tr_mode |= 128; pp_launch<true, true, PP_EPI_F32, true>(p, grid, stream); SMX_CHECK_LAUNCH(); }
+        PP_GO(true, true, PP_EPI_F32)
+    }
     PP_GO(true, false, PP_EPI_F32)
 #undef PP_GO
 }

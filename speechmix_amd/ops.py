@@ -71,6 +71,9 @@ def _pp_applicable(p, dtype):
         return False
     if (p.K & 7) and not (p.a_rc and p.b_rc):
         return False
+    # rows-contiguous operands through a batched view: instantiated for the (RC, RC) layout only (conv weight gradients)
+    if not (p.a_rc and p.b_rc) and ((p.a_rc and p.a.rows_per_batch > 0) or (p.b_rc and p.b.rows_per_batch > 0)):
+        return False
     kst = (p.K + 63) // 64
     per = (kst + p.split_k - 1) // p.split_k
     if (p.split_k - 1) * per >= kst:

@@ -78,3 +78,31 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_pingpong_gemm_isa_has_no_spills_and_no_queue_drain():
+    """The ping-pong GEMM's schedule depends on two properties of the generated code that a source edit can silently
+    break: no register spills (a scratch reload makes hipcc wait vmcnt(0), draining the LDS-DMA prefetch
+    every K tile) and no compiler-inserted vmcnt wait in front of the K loop's first LDS read (any VMEM operation hipcc
+    still tracks there - an epilogue load consumed on only some paths - has the same effect).  Checked on the ISA of every
+    instantiation (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(ROOT, "speechmix_amd", "csrc", "gemm_pp.hip")
+    asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "-I", os.path.dirname(src),
+                          "-S", "--cuda-device-only", src, "-o", "-"], capture_output=True, text=True, check=True).stdout
+    kernels = re.findall(r"^(_Z19gemm_bf16_pp_kernel\w+):.*?s_endpgm", asm, flags=re.M | re.S)
+    bodies = re.findall(r"^_Z19gemm_bf16_pp_kernel\w+:.*?s_endpgm", asm, flags=re.M | re.S)
+    assert len(bodies) >= 9, len(bodies)
+    for name, body in zip(kernels, bodies):
+        assert "scratch_" not in body, f"{name}: register spill"
+        lines = body.splitlines()
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        lo, hi = max(0, mf[0] - 120), mf[-1]               # the K loop (its cold work-list path included)
+        in_asm, bad = False, []
+        for l in lines[lo:hi]:
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif not in_asm and "s_waitcnt" in l and "vmcnt" in l:
+                bad.append(l.strip())
+        assert not bad, f"{name}: compiler-inserted VMEM wait inside the K loop: {bad}"
