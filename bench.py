@@ -187,9 +187,15 @@ def main():
             # HBM-side bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py)
             pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
             if os.path.exists(pmc):
-                k = json.load(open(pmc))["kernels"].get(kname.split(" ")[0])
-                if k:
-                    line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                # PMC keys carry every template argument ("gemm_bf16_pp_kernel<true,true,3,0,false>"): match on the kernel
+                # name and its two layout arguments, launch-weighted over the instantiations
+                base = kname.split(" ")[0]
+                stem, targs = base.split("<")[0], base.split("<")[1].rstrip(">")
+                hits = [v for k, v in json.load(open(pmc))["kernels"].items()
+                        if k.split("<")[0] == stem and k.split("<")[1].startswith(targs)]
+                n = sum(v["launches"] for v in hits)
+                if n:
+                    line["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n)
                     line["roofline"]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
             line["gemm_variants"] = {ops.GemmProfile.name(k): {"tflops": round(v["tflops"], 1),
                                                                   "ms_per_step": round(v["total_ms"] / args.steps, 3),
