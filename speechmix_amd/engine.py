@@ -153,7 +153,7 @@ class Engine:
         slabs, so the trial runs are side-effect free); the slab sum then lands in `out`."""
         n = No * Ko
         cands = [(1, self._split(No, Ko, Kred))]
-        if self.dt == BF16 and ops.PP_MODE != "0" and cv is None:
+        if self.dt == BF16 and ops.pp_allowed() and cv is None:
             sp = ops.pp_split(No, Ko, Kred)
             if ((No + 255) // 256) * ((Ko + 255) // 256) * sp >= 96 and sp > 1:
                 cands.append((8, sp))
@@ -1193,6 +1193,13 @@ class Engine:
                     parts={k: lo[k] for k in ("ce", "kld", "mse") if k in lo})
 
     def backward(self, gscale=1.0, zero_grads=True):
+        ops.IN_BACKWARD = True           # kernel choice: see ops.PP_CONCURRENT_BACKWARD_OK
+        try:
+            self._backward(gscale, zero_grads)
+        finally:
+            ops.IN_BACKWARD = False
+
+    def _backward(self, gscale, zero_grads):
         sv = self.saved
         if sv is None or sv["dlogits"] is None:
             raise RuntimeError("backward() needs a forward() with labels")

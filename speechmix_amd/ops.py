@@ -64,6 +64,17 @@ def _gemm_params(a, b, c, M, N, K, a_rc=False, b_rc=False, av=None, bv=None, cv=
 # SMX_GEMM_PP = auto (default) | 0 (128x128 only) | 1 (ping-pong whenever it is applicable).
 PP_MODE = os.environ.get("SMX_GEMM_PP", "auto")
 _TUNED = {}
+# The ping-pong kernel needs a whole CU per workgroup (160 KB of LDS, the full register file).  A kernel running beside it
+# - RCCL's all-reduce of the gradient buckets on the side stream during backward - takes CUs away, and the displaced
+# workgroups then run as a second round (up to 2x the launch time), where the 4-workgroup/CU kernel only loses a quarter of
+# those CUs.  StepRunner clears this flag when gradients are all-reduced concurrently (world size > 1); forward launches
+# (nothing runs beside them) keep the choice.  SMX_GEMM_PP=1 overrides.
+PP_CONCURRENT_BACKWARD_OK = True
+IN_BACKWARD = False
+
+
+def pp_allowed():
+    return PP_MODE != "0" and (PP_MODE == "1" or PP_CONCURRENT_BACKWARD_OK or not IN_BACKWARD)
 
 
 def _pp_applicable(p, dtype):
@@ -101,7 +112,7 @@ def _time_mode(p, dtype, mode, reps=3):
 
 def _choose_mode(p, dtype):
     """-> tr_mode for this launch (1 or 8)."""
-    if PP_MODE == "0" or not _pp_applicable(p, dtype):
+    if not pp_allowed() or not _pp_applicable(p, dtype):
         return 1
     if PP_MODE == "1":
         return 8

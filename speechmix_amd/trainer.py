@@ -67,6 +67,8 @@ class StepRunner:
         self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, model.num_speech_encoder_layers),
                                    force_comm=force_comm)
         self.engine.stage_cb = self.reducer.stage_done
+        if self.world > 1 or force_comm:
+            ops.PP_CONCURRENT_BACKWARD_OK = False   # RCCL runs beside backward: one-workgroup-per-CU kernels would be displaced
         self.store.external_updates = False          # this runner keeps the bf16 compute copies fresh itself
         self.store.refresh_shadow(force=True)
 
