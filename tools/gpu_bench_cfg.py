@@ -21,7 +21,7 @@ g = torch.Generator().manual_seed(0)
 wave = (torch.randn(B, 160000, generator=g) * 0.1).clamp_(-1, 1).cuda()
 labels = torch.randint(4, V, (B, 32), generator=g).cuda()
 text = torch.randint(4, V, (B, 33), generator=g).cuda() if cfg == "5" else None
-runner = StepRunner(model, lr=1e-5)
+runner = StepRunner(model, lr=1e-5, optimizer=os.environ.get("SMX_OPT", "adafactor"))
 print(f"cfg {cfg}: params {model.store.total/1e6:.1f} M, trainable ranges {len(runner.ranges)}", flush=True)
 for i in range(2):
     loss = runner.step(wave, labels, text_input_ids=text)
