@@ -448,7 +448,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
     const float rrc = 1.0f / (float)max(p.c.rows_per_batch, 1), rre = 1.0f / (float)max(p.e.rows_per_batch, 1);
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
-    constexpr int GA = EPI == PP_EPI_F32 ? 2 : 4;     // row blocks per group (x 2 halves = pieces whose side inputs are in flight)
+    constexpr int GA = (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT) ? 2 : 4;   // row blocks per group (x 2 halves = pieces in registers at once)
 #pragma unroll
     for (int grp = 0; grp < 8 / GA; ++grp) {
         long long cb[GA], eb[GA];
@@ -493,6 +493,10 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
                         asm volatile("" : "+v"(accum[a][ch][h].x), "+v"(accum[a][ch][h].y), "+v"(accum[a][ch][h].z),
                                      "+v"(accum[a][ch][h].w));
             }
+        // all the arithmetic of the group first (independent chains the compiler can interleave: the inline-asm stores
+        // are ordering points), results packed in registers, then the stores back to back
+        uint4 outv[GA][2], auxv[EPI == PP_EPI_ACT ? GA : 1][2];
+        float4 outf[EPI == PP_EPI_F32 ? GA : 1][2][2];
 #pragma unroll
         for (int a = 0; a < GA; ++a) {
             const int a8 = grp * GA + a;
@@ -500,7 +504,6 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 const int n = nl + ch * 32;
-                if (!(rok[a] && n < p.N)) continue;
                 float x[8] = {acc[a8][2 * ch][0], acc[a8][2 * ch][1], acc[a8][2 * ch][2], acc[a8][2 * ch][3],
                               acc[a8][2 * ch + 1][0], acc[a8][2 * ch + 1][1], acc[a8][2 * ch + 1][2], acc[a8][2 * ch + 1][3]};
 #pragma unroll
@@ -510,11 +513,12 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
                         x[0] += accum[a][ch][0].x; x[1] += accum[a][ch][0].y; x[2] += accum[a][ch][0].z; x[3] += accum[a][ch][0].w;
                         x[4] += accum[a][ch][1].x; x[5] += accum[a][ch][1].y; x[6] += accum[a][ch][1].z; x[7] += accum[a][ch][1].w;
                     }
-                    st8<true>(reinterpret_cast<float*>(p.C) + cb[a] + ch * 32, x);
+                    outf[a][ch][0] = make_float4(x[0], x[1], x[2], x[3]);
+                    outf[a][ch][1] = make_float4(x[4], x[5], x[6], x[7]);
                     continue;
                 }
                 if (EPI == PP_EPI_ACT) {
-                    if (p.aux_out) st8<true>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[a] + ch * 32, x);
+                    auxv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
                     act_fwd8(x, p.act);
                 }
                 if (EPI == PP_EPI_ACTGRAD) {
@@ -536,9 +540,25 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
                     x[4] += __uint_as_float(u.z << 16); x[5] += __uint_as_float(u.z & 0xffff0000u);
                     x[6] += __uint_as_float(u.w << 16); x[7] += __uint_as_float(u.w & 0xffff0000u);
                 }
-                st8<true>(reinterpret_cast<bf16_t*>(p.C) + cb[a] + ch * 32, x);
+                outv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
             }
         }
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                if (!(rok[a] && nl + ch * 32 < p.N)) continue;
+                if (EPI == PP_EPI_F32) {
+                    float* c = reinterpret_cast<float*>(p.C) + cb[a] + ch * 32;
+                    st_b128(c, make_uint4(__float_as_uint(outf[a][ch][0].x), __float_as_uint(outf[a][ch][0].y),
+                                          __float_as_uint(outf[a][ch][0].z), __float_as_uint(outf[a][ch][0].w)));
+                    st_b128(c + 4, make_uint4(__float_as_uint(outf[a][ch][1].x), __float_as_uint(outf[a][ch][1].y),
+                                              __float_as_uint(outf[a][ch][1].z), __float_as_uint(outf[a][ch][1].w)));
+                    continue;
+                }
+                if (EPI == PP_EPI_ACT && p.aux_out) st_b128(reinterpret_cast<bf16_t*>(p.aux_out) + eb[a] + ch * 32, auxv[a][ch]);
+                st_b128(reinterpret_cast<bf16_t*>(p.C) + cb[a] + ch * 32, outv[a][ch]);
+            }
     }
 }
 
