@@ -364,408 +364,6 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) 
     }   // tile loop
 }
 
-// ------------------------------------------------------------------------------------------------
-// bf16, big-tile double-buffered variant: (WM*64) x (WN*64) x 64 tile, WM*WN waves of 64x64 each, ONE workgroup
-// per CU.  128x128 tiles are bound by the L2->LDS fill (32 KB per 2.1 MFLOP); a 256x256 tile halves the fill
-// per flop.  Two LDS stages; the next stage's LDS-DMA is issued right after the per-step barrier and lands
-// while the 16 waves (4 per SIMD) run the current stage's MFMAs:
-//   step ks:  s_waitcnt vmcnt(0) (stage ks landed) ; s_barrier ; issue(stage ks+1) ; ds_read + 32 MFMA x 2
-// The barrier publishes stage ks and guarantees every wave is done reading stage ks-1 - the slot being refilled.
-// The DMA is issued from inline asm so that hipcc neither drains it before the ds_reads nor before the barrier.
-// ------------------------------------------------------------------------------------------------
-
-template <bool RC, int ROWS, int NW>   // ROWS: tile rows (KC) / columns (RC) of this operand; NW waves in the workgroup
-struct BigLoader {
-    static constexpr int KC_ROWS = NW * 8;                   // rows filled per pass (KC)
-    static constexpr int RC_KP = NW * 4 > 64 ? 64 : NW * 4;  // k-rows filled per pass of one [64][128] sub-image (RC)
-    static constexpr int RC_PP = 64 / RC_KP;                 // passes per sub-image
-    static constexpr int NP = RC ? (ROWS / 128) * RC_PP : ROWS / KC_ROWS;
-    const bf16_t* ptr[NP];
-    int inc[NP];
-    int kc;
-    int rb[NP], rt[NP];
-    const bf16_t* base;
-    const bf16_t* zero;
-
-    __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& v, int row0, int nrows, int k0, int tid) {
-        base = b;
-        zero = reinterpret_cast<const bf16_t*>(smx_zero_page);
-        const int lane = tid & 63, wave = tid >> 6;
-        kc = 0;
-        if (!RC) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int rl = p * KC_ROWS + wave * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ ((rl >> 1) & 7);
-                if (p == 0) kc = c * 8;
-                const bool ok = row0 + rl < nrows;
-                ptr[p] = ok ? b + view_off(v, row0 + rl) + c * 8 + k0 : zero;
-                inc[p] = ok ? BK : 0;
-            }
-        } else {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int k = k0 + (p % RC_PP) * RC_KP + (wave * 4) % 64 + (lane >> 4);
-                if (v.rows_per_batch > 0) { rb[p] = k / v.rows_per_batch; rt[p] = k - rb[p] * v.rows_per_batch; }
-                else { rb[p] = 0; rt[p] = k; }
-            }
-        }
-    }
-    __device__ __forceinline__ void issue(char* tile, const SmxRowView& v, int row0, int nrows, int k0, int K, int tid) {
-        const int lane = tid & 63, wave = tid >> 6;
-        if (!RC) {
-            const bool kin = k0 + kc < K;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                glds16_asm(kin ? ptr[p] : zero, tile + (p * KC_ROWS + wave * 8) * 128);
-                ptr[p] += inc[p];
-            }
-        } else {
-            // [64 k][ROWS cols] as ROWS/128 side-by-side [64][128] images of 16 KB
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int si = p / RC_PP;
-                const int kl = (p % RC_PP) * RC_KP + (wave * 4) % 64 + (lane >> 4);
-                const int g16 = lane & 15;
-                const int c = row0 + si * 128 + ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
-                const bf16_t* src = zero;
-                if (k0 + kl < K && c < nrows)
-                    src = base + v.off + (long long)rb[p] * v.batch_stride + (long long)rt[p] * v.ld + c;
-                glds16_asm(src, tile + si * 16384 + ((p % RC_PP) * RC_KP + (wave * 4) % 64) * 256);
-                rt[p] += BK;
-                if (v.rows_per_batch > 0) {
-                    while (rt[p] >= v.rows_per_batch) { rt[p] -= v.rows_per_batch; rb[p] += 1; }
-                }
-            }
-        }
-    }
-};
-
-template <bool RC>
-__device__ __forceinline__ bf16x8_t big_frag(const char* tile, int r, int kk, int lane) {
-    if (!RC) return load_frag<false>(tile, r, kk, lane, 1);
-    return load_frag<true>(tile + (r >> 7) * 16384, r & 127, kk, lane, 1);
-}
-
-template <bool A_RC, bool B_RC, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_big_kernel(SmxGemmParams p) {
-    constexpr int TBM = WM * 64, TBN = WN * 64, NW = WM * WN;
-    constexpr int A_BYTES = TBM * 128, ST_BYTES = (TBM + TBN) * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ntn = (p.N + TBN - 1) / TBN, ntm = (p.M + TBM - 1) / TBM;
-    const int nwg = ntn * ntm;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
-    int tm, tn;
-    {
-        const int per_group = GROUP_N * ntm;
-        const int grp = wg / per_group, rem = wg - grp * per_group;
-        const int first = grp * GROUP_N;
-        const int gsz = min(ntn - first, GROUP_N);
-        tm = rem / gsz;
-        tn = first + (rem - tm * gsz);
-    }
-    const int m0 = tm * TBM, n0 = tn * TBN;
-    const int z = blockIdx.z;
-    const int zb = z / p.split_k, zs = z - zb * p.split_k;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
-    const long long zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride, zbias = (long long)zb * p.batch_bias,
-                    ze = (long long)zb * p.batch_e;
-    const int ksteps_total = (p.K + BK - 1) / BK;
-    const int per = (ksteps_total + p.split_k - 1) / p.split_k;
-    const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
-    if (ks0 >= ks1 && p.split_k > 1 && p.atomic == 1) return;
-    const int nk = max(ks1 - ks0, 0);
-
-    BigLoader<A_RC, TBM, NW> la;
-    BigLoader<B_RC, TBN, NW> lb;
-    la.init(A, p.a, m0, p.M, ks0 * BK, tid);
-    lb.init(B, p.b, n0, p.N, ks0 * BK, tid);
-
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    if (nk > 0) {
-        la.issue(smem, p.a, m0, p.M, ks0 * BK, p.K, tid);
-        lb.issue(smem + A_BYTES, p.b, n0, p.N, ks0 * BK, p.K, tid);
-    }
-    for (int i = 0; i < nk; ++i) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        char* cur = smem + (i & 1) * ST_BYTES;
-        if (i + 1 < nk) {
-            char* nxt = smem + ((i + 1) & 1) * ST_BYTES;
-            la.issue(nxt, p.a, m0, p.M, (ks0 + i + 1) * BK, p.K, tid);
-            lb.issue(nxt + A_BYTES, p.b, n0, p.N, (ks0 + i + 1) * BK, p.K, tid);
-        }
-        const char* tA = cur;
-        const char* tB = cur + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[4], fb[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = big_frag<A_RC>(tA, wm * 64 + a * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = big_frag<B_RC>(tB, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[a], acc[a][j], 0, 0, 0);
-        }
-    }
-    const int g = lane >> 4, i16 = lane & 15;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[a][j][0], acc[a][j][1], acc[a][j][2], acc[a][j][3]};
-            epilogue4<bf16_t>(p, zc, zbias, ze, m0 + wm * 64 + a * 16 + i16, n0 + wn * 64 + j * 16 + 4 * g, v);
-        }
-}
-
-template <int WM, int WN>
-static int launch_big(const SmxGemmParams& p, hipStream_t stream) {
-    constexpr int TBM = WM * 64, TBN = WN * 64;
-    const size_t ldsz = 2 * (TBM + TBN) * 128;
-    dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN), 1, p.nbatch * p.split_k);
-    dim3 block(WM * WN * 64);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<false, false, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<false, true, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<true, false, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<true, true, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        attr_done = true;
-    }
-    if (!p.a_rc && !p.b_rc) hipLaunchKernelGGL((gemm_bf16_big_kernel<false, false, WM, WN>), grid, block, ldsz, stream, p);
-    else if (!p.a_rc && p.b_rc) hipLaunchKernelGGL((gemm_bf16_big_kernel<false, true, WM, WN>), grid, block, ldsz, stream, p);
-    else if (p.a_rc && !p.b_rc) hipLaunchKernelGGL((gemm_bf16_big_kernel<true, false, WM, WN>), grid, block, ldsz, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_big_kernel<true, true, WM, WN>), grid, block, ldsz, stream, p);
-    SMX_CHECK_LAUNCH();
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16, 256x256x64 tile, 8 waves (2 x 4, 128 x 64 per wave, 128 accumulator registers), phase-pipelined:
-// every K tile is processed in 4 phases of 16 MFMAs (one 64x32 quadrant of the wave's output x K=64), and
-// each phase also issues ONE 16-KB half-tile of the NEXT K tile by LDS-DMA.  Half-tiles are cut so that a
-// phase only needs what was issued >= 2 phases earlier:
-//     AH0 = first 64 rows of each wave-row-group, AH1 = second 64 rows;  BH0 / BH1 = first / second 32 columns
-//     of each wave-column-group;  quadrant order (rh,ch) = (0,0) (0,1) (1,1) (1,0)
-//     phase 0 needs AH0+BH0 (issues AH0'), phase 1 needs BH1 (issues BH0'), phase 2 needs AH1 (issues BH1'),
-//     phase 3 re-uses BH0 (issues AH1').
-// One counted wait (s_waitcnt vmcnt(4): the two youngest half-tiles may still be in flight) + one raw s_barrier
-// per phase; the DMA is inline asm so hipcc adds no vmcnt(0) of its own.  LDS: 2 stages x 4 half-tiles x 16 KB.
-// Fill per flop is half of the 128x128 kernel's and fragments are re-used from registers across phases.
-// ------------------------------------------------------------------------------------------------
-#define QBM 256
-#define QBN 256
-#define Q_HALF 16384
-#define Q_STAGE (4 * Q_HALF)
-
-template <bool RC, bool IS_A>
-struct HalfLoader {
-    // one half-tile = 128 logical rows (KC) / columns (RC); 512 threads x 2 DMA instructions
-    const bf16_t* base;
-    const bf16_t* zero;
-    SmxRowView v;
-    int row0, nrows, K;
-    long long koff[2][2];     // KC: [half][pass] element offset of my row (chunk folded in), -1 = out of range
-    int kc;                   // KC: k offset of my chunk inside a K tile
-
-    __device__ __forceinline__ int grow(int h, int hr) const {   // half-tile row -> tile row
-        return IS_A ? ((hr >> 6) * 128 + h * 64 + (hr & 63)) : ((hr >> 5) * 64 + h * 32 + (hr & 31));
-    }
-    __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& vv, int r0, int nr, int Kk, int tid) {
-        base = b; v = vv; row0 = r0; nrows = nr; K = Kk;
-        zero = reinterpret_cast<const bf16_t*>(smx_zero_page);
-        const int lane = tid & 63, wave = tid >> 6;
-        kc = 0;
-        if (!RC) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int hr = ps * 64 + wave * 8 + (lane >> 3);
-                    const int c = (lane & 7) ^ ((hr >> 1) & 7);
-                    kc = c * 8;
-                    const int r = row0 + grow(h, hr);
-                    koff[h][ps] = r < nrows ? view_off(v, r) + c * 8 : -1;
-                }
-        }
-    }
-    // issue half h of the K tile starting at k0 into `dst` (16 KB)
-    __device__ __forceinline__ void issue(char* dst, int h, int k0, int tid) const {
-        const int lane = tid & 63, wave = tid >> 6;
-        if (!RC) {
-            const bool kin = k0 + kc < K;
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const long long o = koff[h][ps];
-                glds16_asm((kin && o >= 0) ? base + o + k0 : zero, dst + (ps * 64 + wave * 8) * 128);
-            }
-        } else {
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                const int kl = ps * 32 + wave * 4 + (lane >> 4);
-                const int g16 = lane & 15;
-                const int hc = ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;     // half-tile column of my chunk
-                const int c = row0 + grow(h, hc);
-                const bf16_t* src = zero;
-                if (k0 + kl < K && c < nrows) src = base + view_off(v, k0 + kl) + c;
-                glds16_asm(src, dst + (ps * 32 + wave * 4) * 256);
-            }
-        }
-    }
-};
-
-template <bool RC>
-__device__ __forceinline__ bf16x8_t half_frag(const char* half, int r16, int kk, int lane) {
-    return load_frag<RC>(half, r16, kk, lane, 1);     // both images are [128][..] / [64][128]: same addressing
-}
-
-template <int PH, bool A_RC, bool B_RC>
-__device__ __forceinline__ void q_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4][2], bf16x8_t (&fb)[2][2],
-                                        const HalfLoader<A_RC, true>& la, const HalfLoader<B_RC, false>& lb, char* cur,
-                                        char* nxt, bool more, int k1, int tid, int lane, int wr, int wc) {
-    constexpr int rh = PH >> 1, ch = (PH == 1 || PH == 2) ? 1 : 0;
-    // everything except the two youngest half-tiles has landed (the very last tile drains fully)
-    if (more || PH < 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (more) {
-        if (PH == 0) la.issue(nxt + 0 * Q_HALF, 0, k1, tid);
-        else if (PH == 1) lb.issue(nxt + 2 * Q_HALF, 0, k1, tid);
-        else if (PH == 2) lb.issue(nxt + 3 * Q_HALF, 1, k1, tid);
-        else la.issue(nxt + 1 * Q_HALF, 1, k1, tid);
-    }
-    if (PH == 0 || PH == 2) {       // new A row half: 8 fragment reads
-        const char* ha = cur + rh * Q_HALF;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fa[a][kk] = half_frag<A_RC>(ha, wr * 64 + a * 16, kk, lane);
-    }
-    if (PH != 2) {                  // new B column half: 4 fragment reads (phase 2 keeps BH1)
-        const char* hb = cur + (2 + ch) * Q_HALF;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) fb[j][kk] = half_frag<B_RC>(hb, wc * 32 + j * 16, kk, lane);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[rh * 4 + a][ch * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[a][kk],
-                                                                                      acc[rh * 4 + a][ch * 2 + j], 0, 0, 0);
-}
-
-template <bool A_RC, bool B_RC>
-__global__ __launch_bounds__(512) void gemm_bf16_q_kernel(SmxGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int ntn = (p.N + QBN - 1) / QBN, ntm = (p.M + QBM - 1) / QBM;
-    const int nwg = ntn * ntm;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
-    int tm, tn;
-    {
-        const int per_group = 4 * ntm;
-        const int grp = wg / per_group, rem = wg - grp * per_group;
-        const int first = grp * 4;
-        const int gsz = min(ntn - first, 4);
-        tm = rem / gsz;
-        tn = first + (rem - tm * gsz);
-    }
-    const int m0 = tm * QBM, n0 = tn * QBN;
-    const int z = blockIdx.z;
-    const int zb = z / p.split_k, zs = z - zb * p.split_k;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
-    const long long zc = (long long)zb * p.batch_c + (long long)zs * p.split_stride, zbias = (long long)zb * p.batch_bias,
-                    ze = (long long)zb * p.batch_e;
-    const int ksteps_total = (p.K + BK - 1) / BK;
-    const int per = (ksteps_total + p.split_k - 1) / p.split_k;
-    const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
-    if (ks0 >= ks1 && p.split_k > 1 && p.atomic == 1) return;
-    const int nk = max(ks1 - ks0, 0);
-
-    HalfLoader<A_RC, true> la;
-    HalfLoader<B_RC, false> lb;
-    la.init(A, p.a, m0, p.M, p.K, tid);
-    lb.init(B, p.b, n0, p.N, p.K, tid);
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // LDS: stage s at smem + s*Q_STAGE: [AH0][AH1][BH0][BH1]
-    // prologue: whole K tile 0 in issue order AH0, BH0, BH1, AH1
-    if (nk > 0) {
-        la.issue(smem + 0 * Q_HALF, 0, ks0 * BK, tid);
-        lb.issue(smem + 2 * Q_HALF, 0, ks0 * BK, tid);
-        lb.issue(smem + 3 * Q_HALF, 1, ks0 * BK, tid);
-        la.issue(smem + 1 * Q_HALF, 1, ks0 * BK, tid);
-    }
-    bf16x8_t fa[4][2], fb[2][2];      // A fragments of the current row half (4 row tiles x 2 kk), B of the current col half
-    for (int t = 0; t < nk; ++t) {
-        char* cur = smem + (t & 1) * Q_STAGE;
-        char* nxt = smem + ((t + 1) & 1) * Q_STAGE;
-        const bool more = t + 1 < nk;
-        const int k1 = (ks0 + t + 1) * BK;
-        q_phase<0, A_RC, B_RC>(acc, fa, fb, la, lb, cur, nxt, more, k1, tid, lane, wr, wc);
-        q_phase<1, A_RC, B_RC>(acc, fa, fb, la, lb, cur, nxt, more, k1, tid, lane, wr, wc);
-        q_phase<2, A_RC, B_RC>(acc, fa, fb, la, lb, cur, nxt, more, k1, tid, lane, wr, wc);
-        q_phase<3, A_RC, B_RC>(acc, fa, fb, la, lb, cur, nxt, more, k1, tid, lane, wr, wc);
-    }
-    const int g = lane >> 4, i16 = lane & 15;
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[a][j][0], acc[a][j][1], acc[a][j][2], acc[a][j][3]};
-            const int m = m0 + wr * 128 + (a >> 2) * 64 + (a & 3) * 16 + i16;
-            const int n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + 4 * g;
-            epilogue4<bf16_t>(p, zc, zbias, ze, m, n, v);
-        }
-}
-
-static int launch_q(const SmxGemmParams& p, hipStream_t stream) {
-    const size_t ldsz = 2 * Q_STAGE;
-    dim3 grid(((p.M + QBM - 1) / QBM) * ((p.N + QBN - 1) / QBN), 1, p.nbatch * p.split_k);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_q_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_q_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_q_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_q_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
-        attr_done = true;
-    }
-    if (!p.a_rc && !p.b_rc) hipLaunchKernelGGL((gemm_bf16_q_kernel<false, false>), grid, dim3(512), ldsz, stream, p);
-    else if (!p.a_rc && p.b_rc) hipLaunchKernelGGL((gemm_bf16_q_kernel<false, true>), grid, dim3(512), ldsz, stream, p);
-    else if (p.a_rc && !p.b_rc) hipLaunchKernelGGL((gemm_bf16_q_kernel<true, false>), grid, dim3(512), ldsz, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_q_kernel<true, true>), grid, dim3(512), ldsz, stream, p);
-    SMX_CHECK_LAUNCH();
-}
-
 int smx_gemm_pp(const SmxGemmParams& p, hipStream_t stream);   // gemm_pp.hip
 
 // ------------------------------------------------------------------------------------------------
@@ -930,9 +528,6 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     }
     if (dtype != SMX_BF16) return SMX_EINVAL;
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
-    if (p.tr_mode == 3) return launch_big<4, 2>(p, stream);   // 256 x 128, 8 waves
-    if (p.tr_mode == 5) return launch_big<4, 4>(p, stream);   // 256 x 256, 16 waves
-    if (p.tr_mode == 6) return launch_q(p, stream);           // 256 x 256, 8 waves, phase-pipelined
     if ((p.tr_mode & 255) == 8) return smx_gemm_pp(p, stream);        // 256 x 256, persistent ping-pong
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
     if (p.tr_mode == 1 || p.tr_mode == 4) {   // LDS-DMA fills, 128x128 tile, 4 workgroups / CU

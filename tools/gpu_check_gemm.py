@@ -51,7 +51,7 @@ def main():
         for (M, N, K) in ((200, 136, 72), (128, 128, 64), (257, 384, 200), (96, 50, 328)):
             if dtype == L.BF16:
                 K = (K + 7) // 8 * 8
-            for tr in ((1, 0, 3, 5, 6) if dtype == L.BF16 else (1,)):
+            for tr in ((1, 0) if dtype == L.BF16 else (1,)):
                 Ah = torch.randn(M, K); Bh = torch.randn(N, K)
                 A = Ah.to(tdt).to(dev); B = Bh.to(tdt).to(dev)
                 Af, Bf = A.float().cpu(), B.float().cpu()

@@ -1,5 +1,5 @@
 // GEMM laboratory (not part of the product library): includes the production kernels and times stripped variants of
-// the 128x128x64 LDS-DMA kernel to see which resource bounds it.   hipcc --offload-arch=gfx950 -O3 gemm_lab.hip -o gemm_lab
+// the 128x128x64 LDS-DMA kernel to see which resource bounds it.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ../../speechmix_amd/csrc gemm_lab.hip ../../speechmix_amd/csrc/gemm_pp.hip -o gemm_lab
 #include "../../speechmix_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstdlib>
