@@ -102,6 +102,9 @@ int smx_embed_bwd(const long long* ids, const void* dy, float* dtable, int M, in
 int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream);
 /* same sum in two stages through a caller-owned scratch of smx_colsum_ws_floats(M, N) floats (no atomics; tall inputs) */
 long long smx_colsum_ws_floats(int M, int N);
+/* dropout (same mask as smx_dropout) fused with the column sums of its output: masked gradient + bias gradient in one pass */
+int smx_dropout_colsum(const void* x, void* out, int M, int N, float p, unsigned seed, float* colsum, float alpha, float* ws,
+                       int dtype, hipStream_t stream);
 int smx_colsum_ws(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, float* ws, hipStream_t stream);
 int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream);

@@ -684,6 +684,74 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, lon
         Cvt<T>::st(out + t, Cvt<T>::ld(x + t) * smx_drop_mul(seed, (unsigned)t, th, inv));
     }
 }
+// out = dropout(x) (same mask function and flat index as dropout_kernel) fused with the column sums of out: the backward
+// of a Linear whose output was dropped needs both the masked gradient (operand of its dgrad / wgrad GEMMs) and that
+// gradient's column sums (its bias gradient) - one pass over the tensor instead of two.  Partial rows + colsum_fold_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_colsum_kernel(const T* __restrict__ x, T* __restrict__ out, float* __restrict__ ws,
+                                                             int M, int N, int Np, float p, unsigned seed) {
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 8;
+    const unsigned th = smx_thresh24(p);
+    const float inv = 1.0f / (1.0f - p);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < N) {                                   // N % 8 == 0
+        const int step = gridDim.y * 4;
+        int m = blockIdx.y * 4 + w;
+        for (; m + 3 * step < M; m += 4 * step) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8(x + (long long)(m + u * step) * N + c, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned idx = (unsigned)((long long)(m + u * step) * N + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[u][e] = rt(v[u][e] * smx_drop_mul(seed, idx + e, th, inv), out);
+                    acc[e] += v[u][e];
+                }
+                store8(out + (long long)(m + u * step) * N + c, v[u]);
+            }
+        }
+        for (; m < M; m += step) {
+            float v[8];
+            load8(x + (long long)m * N + c, v);
+            const unsigned idx = (unsigned)((long long)m * N + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = rt(v[e] * smx_drop_mul(seed, idx + e, th, inv), out);
+                acc[e] += v[e];
+            }
+            store8(out + (long long)m * N + c, v);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[w][lane][e] = acc[e];
+    __syncthreads();
+    if (w == 0 && c < N) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+        store8(ws + (long long)blockIdx.y * Np + c, o);
+    }
+}
+// ws: >= smx_colsum_ws_floats(M, N) floats.  colsum[n] += alpha * sum_m out[m, n]
+extern "C" int smx_dropout_colsum(const void* x, void* out, int M, int N, float p, unsigned seed, float* colsum, float alpha,
+                                  float* ws, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || N <= 0 || (N & 7) || p < 0.f || p >= 1.f || !ws || !colsum) return SMX_EINVAL;
+    const int gx = (N + 511) / 512, Np = N;
+    int gy = colsum_slices(M, N);
+    if (gy < 64 && M >= 4096) gy = 64;
+    dim3 grid(gx, gy);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(dropout_colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, ws, M, N, Np, p, seed);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(dropout_colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)out, ws, M, N, Np, p, seed);
+    else return SMX_EINVAL;
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, colsum, gy, N, Np, alpha);
+    SMX_CHECK_LAUNCH();
+}
+
 extern "C" int smx_dropout(const void* x, void* out, long long n, float p, unsigned seed, int dtype, hipStream_t stream) {
     (void)hipGetLastError();
     if (n <= 0 || p < 0.f || p >= 1.f) return SMX_EINVAL;

@@ -57,13 +57,21 @@ class Engine:
         """(p, fresh 32-bit seed) for one dropout site, or None when the site is inactive."""
         return (float(p), int(self.drop_rng.integers(1, 2 ** 32 - 1))) if p and p > 0 else None
 
-    def _dropped(self, dy, drop, n):
-        """dy * (the forward mask of a dropout site): gradient entering the dropped branch."""
-        if drop is None:
-            return dy
+    def _dropped(self, dy, drop, n, bias_grad=None, N=0):
+        """dy * (the forward mask of a dropout site): gradient entering the dropped branch.  bias_grad [N]: also accumulate
+        the column sums of the result (the bias gradient of the Linear whose output was dropped) in the same pass; returns
+        (masked dy, True) then, (dy, False) when nothing was fused."""
+        if bias_grad is None:
+            if drop is None:
+                return dy
+            out = torch.empty_like(dy)
+            ops.dropout(dy, out, n, drop[0], drop[1], self.dt)
+            return out
+        if drop is None or N <= 0 or (N & 7) or os.environ.get("SMX_FUSE_DROPCOL") == "0":       # (env: A/B switch)
+            return self._dropped(dy, drop, n), False
         out = torch.empty_like(dy)
-        ops.dropout(dy, out, n, drop[0], drop[1], self.dt)
-        return out
+        ops.dropout_colsum(dy, out, n // N, N, drop[0], drop[1], bias_grad, self.dt)
+        return out, True
 
     def _stage(self, name):
         if self.stage_cb is not None:
@@ -312,9 +320,10 @@ class Engine:
     def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid):
         """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid)."""
         h, pre, f, d_act, d_out = sv
-        dy = self._dropped(dy, d_out, M * d)
+        gb = self.G(n2[1]) if (n2[1] and self.tr(n2[0])) else None
+        dy, fused = self._dropped(dy, d_out, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, d_out, M * d), False)
         if self.tr(n2[0]):
-            self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=self.G(n2[1]) if n2[1] else None)
+            self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=None if fused else gb)
         dpre = self.new(M, F)
         self.dgrad(dy, self.W(n2[0]), dpre, M, d, F, aux_in=pre, act=act, drop=d_act)
         if self.tr(n1[0]):
@@ -367,9 +376,10 @@ class Engine:
     def _oproj_bwd(self, dy, sv_attn, names, M, d, drop=None):
         """dy: grad wrt the (dropped) out_proj output; returns grad wrt attention output o."""
         wn, bn = names["o"]
-        dy = self._dropped(dy, drop, M * d)
+        gb = self.G(bn) if (bn and self.tr(wn)) else None
+        dy, fused = self._dropped(dy, drop, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, drop, M * d), False)
         if self.tr(wn):
-            self.wgrad(dy, sv_attn["o"], self.G(wn), M, d, d, gb=self.G(bn) if bn else None)
+            self.wgrad(dy, sv_attn["o"], self.G(wn), M, d, d, gb=None if fused else gb)
         do = self.new(M, d)
         self.dgrad(dy, self.W(wn), do, M, d, d)
         return do

@@ -358,6 +358,19 @@ def colsum(x, out, M, N, ld, dtype, alpha=1.0):
 _COLSUM_WS = {}
 
 
+def dropout_colsum(x, out, M, N, p, seed, colsum_out, dtype, alpha=1.0):
+    """out = dropout(x; p, seed) and colsum_out[n] += alpha * sum_m out[m, n] in one pass (N % 8 == 0)."""
+    fn = L.lib().smx_colsum_ws_floats
+    fn.restype = C.c_longlong
+    need = max(int(fn(M, N)), 64 * N)
+    ws = _COLSUM_WS.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = _COLSUM_WS[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)
+    L.check(L.lib().smx_dropout_colsum(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_float(p), C.c_uint(seed),
+                                       C.c_void_p(_ptr(colsum_out)), C.c_float(alpha), C.c_void_p(_ptr(ws)), dtype, _stream()),
+            "smx_dropout_colsum")
+
+
 def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, gscale=1.0, lse=None, logits_t=None,
                   kld=None, kld_scale=0.0):
     p = L.CEParams(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(argmax), _ptr(dlogits), _ptr(lse), M, V, ldl, ldd, gscale,

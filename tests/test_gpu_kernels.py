@@ -40,6 +40,23 @@ def test_colsum_two_stage_and_atomic():
             assert err <= tol * max(1.0, ref.abs().max().item()) * 4, (M, N, dt, err)
 
 
+def test_dropout_colsum_equals_dropout_then_colsum():
+    import torch
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    for (M, N) in ((15968, 768), (1024, 768), (300, 64), (7968, 3072)):
+        for dt, tdt in ((ops.BF16, torch.bfloat16), (ops.F32, torch.float32)):
+            x = torch.randn(M, N, device=dev).to(tdt)
+            o1, o2 = torch.empty_like(x), torch.empty_like(x)
+            ops.dropout(x, o1, M * N, 0.1, 77, dt)
+            s2 = torch.full((N,), 0.25, dtype=torch.float32, device=dev)
+            ops.dropout_colsum(x, o2, M, N, 0.1, 77, s2, dt)
+            assert torch.equal(o1, o2)
+            ref = 0.25 + o1.double().sum(0)
+            assert (s2.double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) * 4
+
+
 def test_adafactor_flat_step_matches_oracle():
     """smx_adafactor_step over a flat buffer of model-shaped tensors vs the oracle restatement of HF Adafactor (pinned to
     the HF class in tests/test_oracle_golden.py): three steps, one tensor without a gradient in step 2, global-norm
