@@ -189,3 +189,52 @@ def test_collator_restates_reference_padding_rules():
     # CPU prefetcher is a pass-through iterator
     out = list(DevicePrefetcher([b, b], "cpu"))
     assert len(out) == 2 and out[0]["labels"] is b["labels"]
+
+
+def test_local_hf_checkpoint_directories_load_by_key_name(tmp_path):
+    """checkpoints written by HuggingFace's own `save_pretrained` (the format of every pretrained
+    backbone the reference names) must load by parameter name: every tensor of the HF speech encoder and of the HF LM is
+    found in the drop-in model with identical values (incl. the tied embedding and the weight-norm parametrisation keys)."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import BartConfig, BartForConditionalGeneration, Wav2Vec2Config, Wav2Vec2Model
+    from speechmix_amd.model import SpeechMixEED
+    torch.manual_seed(0)
+    ecfg = Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                          conv_dim=[32] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, vocab_size=32)
+    lcfg = BartConfig(vocab_size=96, d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                      decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, max_position_embeddings=64,
+                      pad_token_id=1, bos_token_id=0, eos_token_id=2, decoder_start_token_id=2)
+    enc, lm = Wav2Vec2Model(ecfg), BartForConditionalGeneration(lcfg)
+    enc_dir, lm_dir = str(tmp_path / "wav2vec2-tiny"), str(tmp_path / "bart-tiny")
+    enc.save_pretrained(enc_dir, safe_serialization=True)
+    lm.save_pretrained(lm_dir, safe_serialization=True)
+    with warnings_ignored():
+        model = SpeechMixEED(enc_dir, lm_dir, down_scale=2)
+    own = model.state_dict()
+    checked = 0
+    for k, v in enc.state_dict().items():
+        if k.startswith("masked_spec_embed") or "weight" in k or "bias" in k:
+            name = "encoder_model." + k
+            assert name in own, name
+            assert torch.equal(own[name].float().cpu(), v.float()), name
+            checked += 1
+    for k, v in lm.state_dict().items():
+        if k in ("final_logits_bias",):
+            continue
+        name = "decoder_model." + k
+        assert name in own, name
+        assert torch.equal(own[name].float().cpu(), v.float()), name
+        checked += 1
+    assert checked > 100
+
+
+def warnings_ignored():
+    import contextlib
+    import warnings
+
+    @contextlib.contextmanager
+    def cm():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            yield
+    return cm()
