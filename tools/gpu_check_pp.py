@@ -31,6 +31,10 @@ def cmp(name, got, ref, tol=2e-2):
     return ok
 
 
+TRS = tuple(int(x) for x in os.environ.get("SMX_CHECK_TRS", "8").split(","))
+KC_ONLY = (12,)          # kernels that only take K-contiguous operands
+
+
 def main():
     torch.manual_seed(0)
     ok = True
@@ -45,7 +49,7 @@ def main():
         bias = torch.randn(N, device=dev)
         R = torch.randn(M, N, device=dev).bfloat16()
         P = torch.randn(M, N, device=dev).bfloat16()
-        for tr in (8,):
+        for tr in TRS:
             for rep in range(3 if not quick else 2):
                 # fwd: bias + gelu + aux + resid + dropout
                 Y1 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev); X1 = torch.zeros_like(Y1)
@@ -54,11 +58,15 @@ def main():
                 ops.gemm(A, Wm, Y1, M, N, K, ops.BF16, aux_out=X1, tr_mode=1, **kw)
                 ops.gemm(A, Wm, Y2, M, N, K, ops.BF16, aux_out=X2, tr_mode=tr, **kw)
                 ok &= cmp(f"fwd {M}x{N}x{K} tr{tr} rep{rep} out", Y2, Y1) and cmp("    aux", X2, X1)
+                if tr in KC_ONLY:
+                    continue
                 # dgrad: W rows-contiguous, aux_in gelu'
                 Y1.zero_(); Y2.zero_()
                 ops.gemm(A, Wt, Y1, M, N, K, ops.BF16, b_rc=True, bv=view(N), aux_in=P, act=ACT_GELU, tr_mode=1)
                 ops.gemm(A, Wt, Y2, M, N, K, ops.BF16, b_rc=True, bv=view(N), aux_in=P, act=ACT_GELU, tr_mode=tr)
                 ok &= cmp(f"dgrad {M}x{N}x{K} tr{tr} rep{rep}", Y2, Y1)
+            if tr in KC_ONLY:
+                continue
             # wgrad-like: C[N, K] = Y^T[M,N] A[M,K] reduction over M, split-K slabs
             Yb = torch.randn(M, N, device=dev).bfloat16()
             kst = (M + 63) // 64
@@ -74,14 +82,14 @@ def main():
     To = (T - k) // s + 1
     x = torch.randn(Bz, T, Cin, device=dev).bfloat16()
     w = (torch.randn(Cout, k * Cin, device=dev) * 0.1).bfloat16()
-    for tr in (8,):
+    for tr in TRS:
         y1 = torch.zeros(Bz * To, Cout, dtype=torch.bfloat16, device=dev); y2 = torch.zeros_like(y1)
         ops.gemm(x, w, y1, Bz * To, Cout, k * Cin, ops.BF16, av=view(s * Cin, To, T * Cin), tr_mode=1)
         ops.gemm(x, w, y2, Bz * To, Cout, k * Cin, ops.BF16, av=view(s * Cin, To, T * Cin), tr_mode=tr)
         ok &= cmp(f"conv view tr{tr}", y2, y1)
         dy = torch.randn(Bz * To, Cout, device=dev).bfloat16()
         d1 = torch.zeros(3, Cout, k * Cin, dtype=torch.float32, device=dev); d2 = torch.zeros_like(d1)
-        for d, t in ((d1, 1), (d2, tr)):
+        for d, t in ((d1, 1), (d2, 8 if tr in KC_ONLY else tr)):
             ops.gemm(dy, x, d, Cout, k * Cin, Bz * To, ops.BF16, a_rc=True, b_rc=True, av=view(Cout), bv=view(s * Cin, To, T * Cin),
                      out_f32=True, split_k=3, split_stride=Cout * k * Cin, tr_mode=t)
         ok &= cmp(f"conv wgrad view tr{tr}", d2.sum(0), d1.sum(0), 1e-3)
@@ -107,11 +115,12 @@ def main():
         bias = torch.randn(N, device=dev)
         fl = 2.0 * M * N * K
         line = []
-        for tr in (1, 8):
+        for tr in (1,) + TRS:
             t0 = bench(lambda: ops.gemm(A, Wm, Y, M, N, K, ops.BF16, tr_mode=tr))
             t1 = bench(lambda: ops.gemm(A, Wm, Y, M, N, K, ops.BF16, bias=bias, act=ACT_GELU, aux_out=P, tr_mode=tr))
             t2 = bench(lambda: ops.gemm(A, Wm, Y, M, N, K, ops.BF16, bias=bias, resid=R, drop=(0.1, 7), tr_mode=tr))
-            t3 = bench(lambda: ops.gemm(A, Wt, Y, M, N, K, ops.BF16, b_rc=True, bv=view(N), aux_in=P, act=ACT_GELU, tr_mode=tr))
+            t3 = bench(lambda: ops.gemm(A, Wt, Y, M, N, K, ops.BF16, b_rc=True, bv=view(N), aux_in=P, act=ACT_GELU,
+                                        tr_mode=8 if tr in KC_ONLY else tr))
             line.append(f"tr{tr}: plain {t0:.0f}us {fl/t0/1e6:.0f}TF | gelu+aux {t1:.0f}us {fl/t1/1e6:.0f}TF | "
                         f"resid+drop {t2:.0f}us {fl/t2/1e6:.0f}TF | dgrad gelu' {t3:.0f}us {fl/t3/1e6:.0f}TF")
         print(f"M={M} N={N} K={K}\n  " + "\n  ".join(line), flush=True)
