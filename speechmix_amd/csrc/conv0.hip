@@ -12,7 +12,13 @@
 //   * exact tap count (template K = 10; a zero-padded 16-tap instance covers other kernels);
 //   * 20 weight + 20 gradient-accumulator registers per thread instead of 256: high occupancy, no spills;
 //   * reductions over time are register-resident per block and leave the block as ONE partial row
-//     (no atomics - device-scope atomics serialise in L2); a second tiny pass sums the partial rows.
+//     (no atomics - device-scope atomics serialise in L2); a second tiny pass sums the partial rows;
+//   * the GroupNorm backward reads dy ONCE: the weight gradient through the normalisation,
+//       dW[c][t] = sum_b a_bc ( G_bc[t] - m1_bc X1_b[t] - m2_bc Q_bc[t] ),   G = sum dz x_t,  m1 = mean dz,  m2 = mean dz xhat,
+//       Q_bc[t] = sum xhat x_t = rstd_bc ( cb_c X1_b[t] + sum_s w[c][s] R_b[s][t] ) - mean_bc rstd_bc X1_b[t],
+//     needs from the pass over dy only G, sum dz and sum dz xhat per (clip, channel); X1_b[t] = sum x_t and the k x k
+//     autocorrelation R_b[s][t] = sum x_s x_t (x_t = the waveform at stride * t' + t) do not depend on the channel and come
+//     from a pass over the 0.64-MB waveform.
 #include "smx_common.h"
 
 #define C0_MAXK 16
@@ -43,7 +49,10 @@ struct SmxConv0Params {
 
 extern "C" int smx_colsum(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, hipStream_t stream);
 
-extern "C" long long smx_conv0_workspace_floats(int B, int C, int k) { return (long long)B * C0_NBMAX * C * (k + 2); }
+// workspace: partial rows of the reduction kernels | per-block waveform correlations | per-clip gradient contributions
+extern "C" long long smx_conv0_workspace_floats(int B, int C, int k) {
+    return (long long)B * C0_NBMAX * C * (k + 2) + (long long)B * C0_NBMAX * (k * k + k) + (long long)B * C * (k + 2);
+}
 
 template <int K>
 struct C0Thread {
@@ -181,9 +190,11 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(SmxConv0Params p) {
     }
 }
 
-// backward pass 1 (group): S1 = sum_t dz, S2 = sum_t dz * xhat  with dz = dy * gelu'(z)
+// backward (group), the one pass over dy: per (clip, channel) G[t] = sum dz x_t, S1 = sum dz, S2 = sum dz xhat with
+// dz = dy * gelu'(z).  The block's sums stay in registers over all its time steps and leave as one partial row
+// [C][k + 2] = G[0..k) | S1 | S2.
 template <typename T, int K>
-__global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(SmxConv0Params p) {
+__global__ __launch_bounds__(256) void conv0_bwd_group_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
     const int b = blockIdx.y, c0 = threadIdx.x * 2;
     const bool active = c0 < p.C;
@@ -192,11 +203,13 @@ __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(SmxConv0Params p) 
     const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C + c0;
     C0Thread<K> th;
     C0Norm nm;
+    smx_f2 s1 = SMX_PK(0.f), s2 = SMX_PK(0.f), acc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) acc[t] = SMX_PK(0.f);
     if (active) {
         th.load(p, c0);
         nm.load(p, b, c0);
     }
-    smx_f2 s1 = SMX_PK(0.f), s2 = SMX_PK(0.f);
     for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
         const int t0 = tile * C0_TT;
         __syncthreads();
@@ -204,39 +217,109 @@ __global__ __launch_bounds__(256) void conv0_bwd_stats_kernel(SmxConv0Params p) 
         __syncthreads();
         if (active) {
             const int ntt = min(C0_TT, p.T0 - t0);
-            smx_f2 a1 = SMX_PK(0.f), a2 = SMX_PK(0.f);
+            smx_f2 a1 = SMX_PK(0.f), a2 = SMX_PK(0.f);          // per-tile sums, then a second level (rounding)
 #pragma unroll 2
             for (int tt = 0; tt < ntt; ++tt) {
+                const float* x = sx + tt * p.stride;
                 const smx_f2 d = load_pair(dY + (long long)(t0 + tt) * p.C);
-                const smx_f2 u = th.conv(sx + tt * p.stride);
+                const smx_f2 u = th.conv(x);
                 const smx_f2 dz = d * gelu_grad2(__builtin_elementwise_fma(u, nm.a, nm.b0));
                 const smx_f2 xh = __builtin_elementwise_fma(u, nm.rs, nm.xo);
                 a1 += dz;
                 a2 = __builtin_elementwise_fma(dz, xh, a2);
+#pragma unroll
+                for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(dz, SMX_PK(x[t]), acc[t]);
             }
             s1 += a1;
             s2 += a2;
         }
     }
-    if (active)
-        *reinterpret_cast<float4*>(p.partials + (((long long)b * p.nb + blockIdx.x) * p.C + c0) * 2) = make_float4(s1[0], s2[0], s1[1], s2[1]);
-}
-
-// dgamma / dbeta from the per-clip sums
-__global__ void conv0_bwd_affine_kernel(SmxConv0Params p) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= p.C) return;
-    double a = 0, g = 0;
-    for (int b = 0; b < p.B; ++b) {
-        a += p.bstats[((long long)b * p.C + c) * 2];
-        g += p.bstats[((long long)b * p.C + c) * 2 + 1];
+    if (active) {
+        float* row = p.partials + ((long long)b * p.nb + blockIdx.x) * ((long long)p.C * (p.k + 2));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* r = row + (long long)(c0 + j) * (p.k + 2);
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+                if (t < p.k) r[t] = acc[t][j];
+            r[p.k] = s1[j];
+            r[p.k + 1] = s2[j];
+        }
     }
-    if (p.dbeta) p.dbeta[c] += (float)a;
-    if (p.dgamma) p.dgamma[c] += (float)g;
 }
 
-// backward pass 2: du (through GroupNorm) then dW[c][t] += sum du * x[stride*t' + t].  The block's sums stay in
-// registers over all its time steps and leave as one partial row [C*k | C]; smx_colsum adds the rows into dw / dcbias.
+// waveform correlations of the block's time steps: R[s][t] = sum x[stride t' + s] x[stride t' + t] (k x k), X1[t] = sum x[stride t' + t]
+__global__ __launch_bounds__(256) void conv0_xcorr_kernel(SmxConv0Params p, float* __restrict__ xpart) {
+    __shared__ float sx[C0_TT * 8 + C0_MAXK];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int xn = p.k * p.k + p.k;
+    const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
+    const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
+    const bool pairs = tid < p.k * p.k;
+    const int s = pairs ? tid / p.k : 0, t = pairs ? tid - s * p.k : tid - p.k * p.k;
+    float acc = 0.f;
+    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
+        const int t0 = tile * C0_TT;
+        __syncthreads();
+        stage_wave(p, sx, b, t0);
+        __syncthreads();
+        if (tid < xn) {
+            const int ntt = min(C0_TT, p.T0 - t0);
+            float a = 0.f;
+            for (int tt = 0; tt < ntt; ++tt) {
+                const float* x = sx + tt * p.stride;
+                a = pairs ? fmaf(x[s], x[t], a) : a + x[t];
+            }
+            acc += a;
+        }
+    }
+    if (tid < xn) xpart[((long long)b * p.nb + blockIdx.x) * xn + tid] = acc;
+}
+
+// per (clip, 16 channels): partial rows -> S1, S2, G (fp64), then this clip's contribution to dW through the GroupNorm
+// (see the file header), written with S1 / S2 as one row [C k | C (dbeta) | C (dgamma)] of `contrib`; bstats gets S1, S2.
+__global__ __launch_bounds__(256) void conv0_bwd_group_finalize_kernel(SmxConv0Params p, const float* __restrict__ xpart,
+                                                                       float* __restrict__ contrib) {
+    __shared__ double xs[C0_MAXK * C0_MAXK + C0_MAXK];
+    __shared__ double sv[16][16];
+    const int b = blockIdx.y, tid = threadIdx.x, cl = tid >> 4, slot = tid & 15;
+    const int c = blockIdx.x * 16 + cl, k = p.k, xn = k * k + k;
+    if (tid < xn) {
+        double a = 0;
+        for (int j = 0; j < p.nb; ++j) a += (double)xpart[((long long)b * p.nb + j) * xn + tid];
+        xs[tid] = a;
+    }
+    double v = 0;
+    if (c < p.C && slot < k + 2)
+        for (int j = 0; j < p.nb; ++j) v += (double)p.partials[((long long)b * p.nb + j) * ((long long)p.C * (k + 2)) + (long long)c * (k + 2) + slot];
+    sv[cl][slot] = v;
+    __syncthreads();
+    if (c >= p.C) return;
+    float* row = contrib + (long long)b * p.C * (k + 2);
+    if (slot < k) {
+        const double S1 = sv[cl][k], S2 = sv[cl][k + 1];
+        const double sum = p.stats[((long long)b * p.C + c) * 2], sq = p.stats[((long long)b * p.C + c) * 2 + 1];
+        const double mean = sum / p.T0;
+        double var = sq / p.T0 - mean * mean;
+        if (var < 0) var = 0;
+        const double rstd = 1.0 / sqrt(var + (double)p.eps);
+        const double a = rstd * (double)p.gamma[c], m1 = S1 / p.T0, m2 = S2 / p.T0;
+        const double x1 = xs[k * k + slot];
+        double ux = p.cbias ? (double)p.cbias[c] * x1 : 0.0;
+        for (int s = 0; s < k; ++s) ux += (double)p.w[c * k + s] * xs[s * k + slot];
+        const double q = rstd * ux - mean * rstd * x1;
+        row[c * k + slot] = (float)(a * (v - m1 * x1 - m2 * q));
+    } else if (slot == k) {
+        row[p.C * k + c] = (float)v;
+        p.bstats[((long long)b * p.C + c) * 2] = v;
+    } else if (slot == k + 1) {
+        row[p.C * k + p.C + c] = (float)v;
+        p.bstats[((long long)b * p.C + c) * 2 + 1] = v;
+    }
+}
+
+// backward, plain mode (dy is du): dW[c][t] += sum du * x[stride*t' + t].  The block's sums stay in registers over all
+// its time steps and leave as one partial row [C*k | C]; smx_colsum adds the rows into dw / dcbias.
 template <typename T, int K>
 __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
     __shared__ float sx[C0_TT * 8 + C0_MAXK];
@@ -245,21 +328,9 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
     const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
     const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
     const T* dY = reinterpret_cast<const T*>(p.dy) + (long long)b * p.T0 * p.C + c0;
-    C0Thread<K> th;
-    C0Norm nm;
-    smx_f2 m1 = SMX_PK(0.f), m2 = SMX_PK(0.f), accb = SMX_PK(0.f), acc[K];
+    smx_f2 accb = SMX_PK(0.f), acc[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) acc[t] = SMX_PK(0.f);
-    if (active && p.group) {
-        th.load(p, c0);
-        nm.load(p, b, c0);
-        const float invT = 1.0f / (float)p.T0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            m1[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2] * invT);
-            m2[j] = (float)(p.bstats[((long long)b * p.C + c0 + j) * 2 + 1] * invT);
-        }
-    }
     for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
         const int t0 = tile * C0_TT;
         __syncthreads();
@@ -270,13 +341,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
 #pragma unroll 2
             for (int tt = 0; tt < ntt; ++tt) {
                 const float* x = sx + tt * p.stride;
-                smx_f2 du = load_pair(dY + (long long)(t0 + tt) * p.C);
-                if (p.group) {
-                    const smx_f2 u = th.conv(x);
-                    const smx_f2 dz = du * gelu_grad2(__builtin_elementwise_fma(u, nm.a, nm.b0));
-                    const smx_f2 xh = __builtin_elementwise_fma(u, nm.rs, nm.xo);
-                    du = nm.a * (dz - m1 - xh * m2);
-                }
+                const smx_f2 du = load_pair(dY + (long long)(t0 + tt) * p.C);
                 accb += du;
 #pragma unroll
                 for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(du, SMX_PK(x[t]), acc[t]);
@@ -352,12 +417,29 @@ extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t st
     conv0_reduction_geometry(p);
     const dim3 grid(p.nb, p.B);
     if (p.group) {
-        if (!p.stats || !p.bstats) return SMX_EINVAL;
-        if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_stats_kernel, float, grid, p, stream);
-        else C0_LAUNCH_TK(conv0_bwd_stats_kernel, bf16_t, grid, p, stream);
-        const int n = p.B * p.C * 2;
-        hipLaunchKernelGGL(conv0_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p.partials, p.bstats, p.B, p.C, p.nb);
-        hipLaunchKernelGGL(conv0_bwd_affine_kernel, dim3((p.C + 255) / 256), dim3(256), 0, stream, p);
+        if (!p.stats || !p.bstats || !p.gamma) return SMX_EINVAL;
+        float* xpart = p.partials + (long long)p.B * C0_NBMAX * p.C * (p.k + 2);
+        float* contrib = xpart + (long long)p.B * C0_NBMAX * (p.k * p.k + p.k);
+        hipLaunchKernelGGL(conv0_xcorr_kernel, grid, dim3(256), 0, stream, p, xpart);
+        if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_group_kernel, float, grid, p, stream);
+        else C0_LAUNCH_TK(conv0_bwd_group_kernel, bf16_t, grid, p, stream);
+        hipLaunchKernelGGL(conv0_bwd_group_finalize_kernel, dim3((p.C + 15) / 16, p.B), dim3(256), 0, stream, p, xpart, contrib);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        const long long ld = (long long)p.C * (p.k + 2);
+        if (p.dw) {
+            rc = smx_colsum(contrib, p.dw, p.B, p.C * p.k, ld, 1.0f, SMX_F32, stream);
+            if (rc) return rc;
+        }
+        if (p.dbeta) {
+            rc = smx_colsum(contrib + (long long)p.C * p.k, p.dbeta, p.B, p.C, ld, 1.0f, SMX_F32, stream);
+            if (rc) return rc;
+        }
+        if (p.dgamma) {
+            rc = smx_colsum(contrib + (long long)p.C * p.k + p.C, p.dgamma, p.B, p.C, ld, 1.0f, SMX_F32, stream);
+            if (rc) return rc;
+        }
+        SMX_CHECK_LAUNCH();
     }
     if (p.dw) {
         if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_w_kernel, float, grid, p, stream);
@@ -367,7 +449,7 @@ extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t st
         const long long ld = (long long)p.C * (p.k + 1);
         rc = smx_colsum(p.partials, p.dw, p.B * p.nb, p.C * p.k, ld, 1.0f, SMX_F32, stream);
         if (rc) return rc;
-        if (p.dcbias && !p.group) {
+        if (p.dcbias) {
             rc = smx_colsum(p.partials + (long long)p.C * p.k, p.dcbias, p.B * p.nb, p.C, ld, 1.0f, SMX_F32, stream);
             if (rc) return rc;
         }
