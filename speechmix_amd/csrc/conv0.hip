@@ -24,6 +24,7 @@
 #define C0_MAXK 16
 #define C0_TT 64        // time steps per LDS stage
 #define C0_NBMAX 64     // reduction kernels: at most this many blocks (partial rows) per clip
+#define C0_CH 8         // backward: rows of dy requested ahead of their use
 
 struct SmxConv0Params {
     const float* wave;    // [B, N] fp32
@@ -218,17 +219,25 @@ __global__ __launch_bounds__(256) void conv0_bwd_group_kernel(SmxConv0Params p) 
         if (active) {
             const int ntt = min(C0_TT, p.T0 - t0);
             smx_f2 a1 = SMX_PK(0.f), a2 = SMX_PK(0.f);          // per-tile sums, then a second level (rounding)
-#pragma unroll 2
-            for (int tt = 0; tt < ntt; ++tt) {
-                const float* x = sx + tt * p.stride;
-                const smx_f2 d = load_pair(dY + (long long)(t0 + tt) * p.C);
-                const smx_f2 u = th.conv(x);
-                const smx_f2 dz = d * gelu_grad2(__builtin_elementwise_fma(u, nm.a, nm.b0));
-                const smx_f2 xh = __builtin_elementwise_fma(u, nm.rs, nm.xo);
-                a1 += dz;
-                a2 = __builtin_elementwise_fma(dz, xh, a2);
+            // C0_CH rows of dy are requested before the first is used: one 256-B row per wave and time step, so the
+            // bytes in flight (not the arithmetic) set this kernel's speed.  Steps past the end read dy as zero (their x
+            // window is staged, zero-filled), so they add nothing.
+            for (int tc = 0; tc < ntt; tc += C0_CH) {
+                smx_f2 d[C0_CH];
 #pragma unroll
-                for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(dz, SMX_PK(x[t]), acc[t]);
+                for (int j = 0; j < C0_CH; ++j)
+                    d[j] = tc + j < ntt ? load_pair(dY + (long long)(t0 + tc + j) * p.C) : SMX_PK(0.f);
+#pragma unroll
+                for (int j = 0; j < C0_CH; ++j) {
+                    const float* x = sx + (tc + j) * p.stride;
+                    const smx_f2 u = th.conv(x);
+                    const smx_f2 dz = d[j] * gelu_grad2(__builtin_elementwise_fma(u, nm.a, nm.b0));
+                    const smx_f2 xh = __builtin_elementwise_fma(u, nm.rs, nm.xo);
+                    a1 += dz;
+                    a2 = __builtin_elementwise_fma(dz, xh, a2);
+#pragma unroll
+                    for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(dz, SMX_PK(x[t]), acc[t]);
+                }
             }
             s1 += a1;
             s2 += a2;
@@ -249,31 +258,41 @@ __global__ __launch_bounds__(256) void conv0_bwd_group_kernel(SmxConv0Params p) 
 }
 
 // waveform correlations of the block's time steps: R[s][t] = sum x[stride t' + s] x[stride t' + t] (k x k), X1[t] = sum x[stride t' + t]
+#define C0_XT 8         // K tiles of time steps staged per round (this kernel has almost no arithmetic: its time is the staging)
 __global__ __launch_bounds__(256) void conv0_xcorr_kernel(SmxConv0Params p, float* __restrict__ xpart) {
-    __shared__ float sx[C0_TT * 8 + C0_MAXK];
+    __shared__ float sx[C0_XT * C0_TT * 8 + C0_MAXK];
+    __shared__ float red[256];
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int xn = p.k * p.k + p.k;
+    const int xn = p.k * p.k + p.k;               // <= 128 entries, each summed by two threads (even / odd time steps)
+    const int e = tid & 127, part = tid >> 7;
     const int ntiles = (p.T0 + C0_TT - 1) / C0_TT;
     const int tile_end = min(ntiles, (int)(blockIdx.x + 1) * p.tiles_per_block);
-    const bool pairs = tid < p.k * p.k;
-    const int s = pairs ? tid / p.k : 0, t = pairs ? tid - s * p.k : tid - p.k * p.k;
+    const bool pairs = e < p.k * p.k;
+    const int s = pairs ? e / p.k : 0, t = pairs ? e - s * p.k : min(e - p.k * p.k, p.k - 1);
     float acc = 0.f;
-    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; ++tile) {
+    for (int tile = blockIdx.x * p.tiles_per_block; tile < tile_end; tile += C0_XT) {
         const int t0 = tile * C0_TT;
+        const int span = min(C0_XT, tile_end - tile) * C0_TT, steps = min(span, p.T0 - t0);
         __syncthreads();
-        stage_wave(p, sx, b, t0);
+        for (int i = tid; i < span * p.stride + C0_MAXK; i += 256) {
+            const int n = t0 * p.stride + i;
+            sx[i] = n < p.N ? p.wave[(long long)b * p.N + n] : 0.f;
+        }
         __syncthreads();
-        if (tid < xn) {
-            const int ntt = min(C0_TT, p.T0 - t0);
+        if (e < xn) {
             float a = 0.f;
-            for (int tt = 0; tt < ntt; ++tt) {
+#pragma unroll 8
+            for (int tt = part; tt < span; tt += 2) {       // (windows past the clip's last step are staged: read, not counted)
                 const float* x = sx + tt * p.stride;
-                a = pairs ? fmaf(x[s], x[t], a) : a + x[t];
+                const float v = pairs ? x[s] * x[t] : x[t];
+                a += tt < steps ? v : 0.f;
             }
             acc += a;
         }
     }
-    if (tid < xn) xpart[((long long)b * p.nb + blockIdx.x) * xn + tid] = acc;
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < xn) xpart[((long long)b * p.nb + blockIdx.x) * xn + tid] = red[tid] + red[tid + 128];
 }
 
 // per (clip, 16 channels): partial rows -> S1, S2, G (fp64), then this clip's contribution to dW through the GroupNorm
@@ -286,11 +305,13 @@ __global__ __launch_bounds__(256) void conv0_bwd_group_finalize_kernel(SmxConv0P
     const int c = blockIdx.x * 16 + cl, k = p.k, xn = k * k + k;
     if (tid < xn) {
         double a = 0;
+#pragma unroll 8
         for (int j = 0; j < p.nb; ++j) a += (double)xpart[((long long)b * p.nb + j) * xn + tid];
         xs[tid] = a;
     }
     double v = 0;
     if (c < p.C && slot < k + 2)
+#pragma unroll 8
         for (int j = 0; j < p.nb; ++j) v += (double)p.partials[((long long)b * p.nb + j) * ((long long)p.C * (k + 2)) + (long long)c * (k + 2) + slot];
     sv[cl][slot] = v;
     __syncthreads();
@@ -338,13 +359,18 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
         __syncthreads();
         if (active) {
             const int ntt = min(C0_TT, p.T0 - t0);
-#pragma unroll 2
-            for (int tt = 0; tt < ntt; ++tt) {
-                const float* x = sx + tt * p.stride;
-                const smx_f2 du = load_pair(dY + (long long)(t0 + tt) * p.C);
-                accb += du;
+            for (int tc = 0; tc < ntt; tc += C0_CH) {       // (loads batched as in conv0_bwd_group_kernel)
+                smx_f2 d[C0_CH];
 #pragma unroll
-                for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(du, SMX_PK(x[t]), acc[t]);
+                for (int j = 0; j < C0_CH; ++j)
+                    d[j] = tc + j < ntt ? load_pair(dY + (long long)(t0 + tc + j) * p.C) : SMX_PK(0.f);
+#pragma unroll
+                for (int j = 0; j < C0_CH; ++j) {
+                    const float* x = sx + (tc + j) * p.stride;
+                    accb += d[j];
+#pragma unroll
+                    for (int t = 0; t < K; ++t) acc[t] = __builtin_elementwise_fma(d[j], SMX_PK(x[t]), acc[t]);
+                }
             }
         }
     }
