@@ -199,8 +199,10 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
         }
         if (p.drop_p > 0.f) {
             const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
+            if (!(idx & 1u)) smx_drop_mul8(p.drop_seed, idx, th, inv_keep, x);
+            else
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
+                for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
         }
         if (resid) {
             float r[8];

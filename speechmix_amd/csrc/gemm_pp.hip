@@ -530,8 +530,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
                 }
                 if (drop) {
                     const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
+                    smx_drop_mul8(p.drop_seed, idx, th, inv_keep, x);        // idx % 8 == 0 (aligned views, N % 8 == 0)
                 }
                 if (EPI == PP_EPI_LINEAR && has_res) {
                     const uint4 u = side[a][ch];

@@ -675,8 +675,7 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, lon
     for (; i + 8 <= n; i += step) {
         float v[8];
         load8(x + i, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= smx_drop_mul(seed, (unsigned)(i + e), th, inv);
+        smx_drop_mul8(seed, (unsigned)i, th, inv, v);              // i % 8 == 0
         store8(out + i, v);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {      // ragged tail (only odd-sized test tensors get here)
@@ -706,9 +705,10 @@ __global__ __launch_bounds__(256) void dropout_colsum_kernel(const T* __restrict
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const unsigned idx = (unsigned)((long long)(m + u * step) * N + c);
+                smx_drop_mul8(seed, idx, th, inv, v[u]);             // idx % 8 == 0 (N % 8 == 0)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[u][e] = rt(v[u][e] * smx_drop_mul(seed, idx + e, th, inv), out);
+                    v[u][e] = rt(v[u][e], out);
                     acc[e] += v[u][e];
                 }
                 store8(out + (long long)(m + u * step) * N + c, v[u]);
@@ -718,9 +718,10 @@ __global__ __launch_bounds__(256) void dropout_colsum_kernel(const T* __restrict
             float v[8];
             load8(x + (long long)m * N + c, v);
             const unsigned idx = (unsigned)((long long)m * N + c);
+            smx_drop_mul8(seed, idx, th, inv, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[e] = rt(v[e] * smx_drop_mul(seed, idx + e, th, inv), out);
+                v[e] = rt(v[e], out);
                 acc[e] += v[e];
             }
             store8(out + (long long)m * N + c, v);

@@ -160,16 +160,30 @@ __device__ __forceinline__ void act_grad_mul8(float x[8], const float pre[8], in
 
 // ---- counter-based dropout: keep(idx) is a pure function of (seed, element index), so backward regenerates
 // the forward mask instead of storing it (TF: nn.functional.dropout sites listed in engine.py) ----
+// 32-bit integer mixes are quarter-rate on the vector unit (v_mul_lo_u32), and the GEMM epilogues hash every output element
+// of a dropped Linear: two multiplies per hash (the "lowbias32" finaliser) and TWO elements per hash (element idx takes the
+// low / high 16 bits of hash(idx >> 1); thresholds are compared at 16 bits: p is honoured to 2^-16).
 __device__ __forceinline__ unsigned smx_hash32(unsigned seed, unsigned idx) {
-    unsigned x = idx * 0x9E3779B1u + seed;
-    x ^= x >> 15; x *= 0x85EBCA77u;
-    x ^= x >> 13; x *= 0xC2B2AE3Du;
+    unsigned x = idx + seed * 0x9E3779B1u;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
     return x;
 }
 // returns the multiplier: 0 (dropped) or 1/(1-p) (kept)
 __device__ __forceinline__ float smx_drop_mul(unsigned seed, unsigned idx, unsigned thresh24, float inv_keep) {
-    return (smx_hash32(seed, idx) >> 8) >= thresh24 ? inv_keep : 0.f;
+    const unsigned h = smx_hash32(seed, idx >> 1);
+    return ((idx & 1u) ? h >> 16 : h & 0xffffu) >= (thresh24 >> 8) ? inv_keep : 0.f;
+}
+// x[e] *= multiplier(idx + e) for 8 consecutive elements starting at an EVEN idx: four hashes
+__device__ __forceinline__ void smx_drop_mul8(unsigned seed, unsigned idx, unsigned thresh24, float inv_keep, float x[8]) {
+    const unsigned th = thresh24 >> 8;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const unsigned h = smx_hash32(seed, (idx >> 1) + (e >> 1));
+        x[e] *= (h & 0xffffu) >= th ? inv_keep : 0.f;
+        x[e + 1] *= (h >> 16) >= th ? inv_keep : 0.f;
+    }
 }
 __host__ __device__ __forceinline__ unsigned smx_thresh24(float p) { return (unsigned)(p * 16777216.0f); }
 
