@@ -276,9 +276,13 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
     }
 }
 
+#ifndef TR1_MINWG
+#define TR1_MINWG 4
+#endif
 template <bool A_RC, bool B_RC>
-__global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) {
+__global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.drop_seed == 0xdead0001u) return;      // LAB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
@@ -358,8 +362,21 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_dma_kernel(SmxGemmParams p) 
         }
         __syncthreads();                 // everyone is done reading before the next fill overwrites the tile
     }
-    // the K loop ended on a barrier: the tile buffers are free, each wave transposes through its own 8-KB slice
-    epilogue_staged(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, zc, zbias, ze, lane);
+    if (p.drop_seed == 0xdead0002u) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[tid] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }   // LAB
+    // the K loop ended on a barrier: the tile buffers are free, each wave transposes through its own 8-KB slice.
+    // The lane id and the parameter block are re-read behind an opaque asm: everything the epilogue derives from them
+    // (LDS addresses, row offsets, flags) is then computed HERE instead of being hoisted above the K loop, where it would
+    // have to live across the loop on a 128-register budget (hipcc spilled a dozen VGPRs to scratch for it, and a kernel
+    // that uses scratch at all pays ~1.3 us more per launch).
+    {
+        int lane_e = lane, wave_e = wave;
+        asm volatile("" : "+v"(lane_e), "+v"(wave_e));
+        wave_e = __builtin_amdgcn_readfirstlane(wave_e);
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const SmxGemmParams& pe = *(const SmxGemmParams*)ka;
+        epilogue_staged(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+    }
     if (lin + (int)gridDim.x < nwg) __syncthreads();   // slices are tile memory again for the next fill
     }   // tile loop
 }

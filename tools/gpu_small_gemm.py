@@ -65,6 +65,9 @@ def ksweep():
         Wm = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
         Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
         F = torch.zeros(M, N, dtype=torch.float32, device=dev)
+        if "lab" in sys.argv:
+            timed(f"ksweep_lab_return K{K} m1", lambda: ops.gemm(A, Wm, Y, M, N, K, ops.BF16, tr_mode=1, drop=(0.0, 0xdead0001)))
+            timed(f"ksweep_lab_noepi K{K} m1", lambda: ops.gemm(A, Wm, Y, M, N, K, ops.BF16, tr_mode=1, drop=(0.0, 0xdead0002)))
         for mode in MODES:
             timed(f"ksweep_bf16out K{K} m{mode}", lambda: ops.gemm(A, Wm, Y, M, N, K, ops.BF16, tr_mode=mode))
             timed(f"ksweep_f32out K{K} m{mode}", lambda: ops.gemm(A, Wm, F, M, N, K, ops.BF16, out_f32=True, tr_mode=mode))
