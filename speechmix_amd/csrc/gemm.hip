@@ -15,6 +15,7 @@
 // images read with the gfx950 transposing read ds_read_b64_tr_b16.  Register-staged double-buffered
 // LDS, one barrier per K step.  fp32 kernel: a deliberately simple, independent VALU tile kernel
 // (parity path + on-device cross-check of the MFMA kernel).
+#include <cstdlib>
 #include "gemm_common.h"
 
 template <typename TOUT>
@@ -276,10 +277,121 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
     }
 }
 
+
+// Specialised form of epilogue_staged for the epilogue classes of gemm_common.h on aligned views (launcher-checked): the
+// same LDS transposition, but per 32-row half the row visits of a lane are batched in pairs - side loads (residual /
+// pre-activation / accumulate target) issued first, all eight LDS reads together, then the arithmetic of the class only,
+// then the stores - with no ragged-tail path and no per-visit flag tests.  The generic form spent ~3.5 us per tile here
+// (a quarter of a K = 768 launch: the workgroups of a CU reach their epilogues together and are bound by VALU issue).
+template <int EPI>
+__device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
+                                                     long long zc, long long zbias, long long ze, int lane) {
+    const int i16 = lane & 15, g = lane >> 4;
+    const int rr = lane >> 3, cc = lane & 7;
+    const int n = nw0 + cc * 8;
+    const bool nok = n < p.N;                          // N % 8 == 0: all 8 columns or none
+    float bs[8];
+    if (p.bias && nok) load8(p.bias + zbias + n, bs);
+    else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+    }
+    const unsigned th = smx_thresh24(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    const bool drop = EPI != PP_EPI_F32 && p.drop_p > 0.f;
+    const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
+    const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
+    const bool has_aux = EPI == PP_EPI_ACT && p.aux_out;
+    constexpr int QB = (EPI == PP_EPI_ACT || EPI == PP_EPI_ACTGRAD) ? 1 : 2;         // row visits per batch: what fits beside the 64 accumulator registers
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lr = i2 * 16 + i16, c = j * 4 + g;
+                *reinterpret_cast<f32x4_t*>(wbuf + lr * 256 + ((c ^ (lr & 15)) << 4)) = acc[2 * h + i2][j];
+            }
+#pragma unroll
+        for (int q0 = 0; q0 < 4; q0 += QB) {
+            long long cb[QB], eb[QB];
+            bool ok[QB];
+            uint4 side[QB];
+            float4 old[EPI == PP_EPI_F32 ? QB : 1][2];
+            f32x4_t lo[QB], hi[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const int lr = (q0 + qi) * 8 + rr, m = mw0 + h * 32 + lr;
+                ok[qi] = nok && m < p.M;
+                const int mm = ok[qi] ? m : 0;
+                cb[qi] = zc + view_off(p.c, mm) + n;
+                eb[qi] = EPI == PP_EPI_F32 ? 0 : ze + view_off(p.e, mm) + n;
+                if (EPI == PP_EPI_ACTGRAD) {
+                    side[qi] = ok[qi] ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + eb[qi]) : make_uint4(0, 0, 0, 0);
+                } else if (EPI == PP_EPI_LINEAR) {
+                    side[qi] = (has_res && ok[qi]) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + eb[qi])
+                                                   : make_uint4(0, 0, 0, 0);
+                } else if (EPI == PP_EPI_F32) {
+                    if (has_acc && ok[qi]) {
+                        const float* c = reinterpret_cast<const float*>(p.C) + cb[qi];
+                        old[qi][0] = *reinterpret_cast<const float4*>(c);
+                        old[qi][1] = *reinterpret_cast<const float4*>(c + 4);
+                    } else {
+                        old[qi][0] = old[qi][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                lo[qi] = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc) ^ (lr & 15)) << 4));
+                hi[qi] = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc + 1) ^ (lr & 15)) << 4));
+            }
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const int m = mw0 + h * 32 + (q0 + qi) * 8 + rr;
+                float x[8] = {lo[qi][0], lo[qi][1], lo[qi][2], lo[qi][3], hi[qi][0], hi[qi][1], hi[qi][2], hi[qi][3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[e]);
+                if (EPI == PP_EPI_F32) {
+                    x[0] += old[qi][0].x; x[1] += old[qi][0].y; x[2] += old[qi][0].z; x[3] += old[qi][0].w;
+                    x[4] += old[qi][1].x; x[5] += old[qi][1].y; x[6] += old[qi][1].z; x[7] += old[qi][1].w;
+                    if (ok[qi]) {
+                        float* c = reinterpret_cast<float*>(p.C) + cb[qi];
+                        *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
+                        *reinterpret_cast<float4*>(c + 4) = make_float4(x[4], x[5], x[6], x[7]);
+                    }
+                    continue;
+                }
+                if (EPI == PP_EPI_ACT) {
+                    if (has_aux && ok[qi])
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[qi]) =
+                            make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
+                    act_fwd8(x, p.act);
+                }
+                if (EPI == PP_EPI_ACTGRAD) {
+                    const uint4 u = side[qi];
+                    float s[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                  __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                    act_grad_mul8(x, s, p.act);
+                }
+                if (drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
+                if (EPI == PP_EPI_LINEAR) {                 // (zeros when there is no residual)
+                    const uint4 u = side[qi];
+                    x[0] += __uint_as_float(u.x << 16); x[1] += __uint_as_float(u.x & 0xffff0000u);
+                    x[2] += __uint_as_float(u.y << 16); x[3] += __uint_as_float(u.y & 0xffff0000u);
+                    x[4] += __uint_as_float(u.z << 16); x[5] += __uint_as_float(u.z & 0xffff0000u);
+                    x[6] += __uint_as_float(u.w << 16); x[7] += __uint_as_float(u.w & 0xffff0000u);
+                }
+                if (ok[qi])
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + cb[qi]) =
+                        make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
+            }
+        }
+    }
+}
+
 #ifndef TR1_MINWG
 #define TR1_MINWG 4
 #endif
-template <bool A_RC, bool B_RC>
+template <bool A_RC, bool B_RC, int EPI = -1>       // EPI: epilogue class (gemm_common.h) on aligned views, -1: generic
 __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.drop_seed == 0xdead0001u) return;      // LAB
@@ -375,7 +487,10 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
         auto ka = __builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         const SmxGemmParams& pe = *(const SmxGemmParams*)ka;
-        epilogue_staged(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+        if constexpr (EPI >= 0)
+            epilogue_staged_fast<EPI>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+        else
+            epilogue_staged(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
     }
     if (lin + (int)gridDim.x < nwg) __syncthreads();   // slices are tile memory again for the next fill
     }   // tile loop
@@ -549,14 +664,27 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
     if (p.tr_mode == 1 || p.tr_mode == 4) {   // LDS-DMA fills, 128x128 tile, 4 workgroups / CU
         const size_t ldsz = STAGE_BYTES;
-        if (!p.a_rc && !p.b_rc)
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, false>), grid, dim3(256), ldsz, stream, p);
-        else if (!p.a_rc && p.b_rc)
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, true>), grid, dim3(256), ldsz, stream, p);
-        else if (p.a_rc && !p.b_rc)
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, false>), grid, dim3(256), ldsz, stream, p);
-        else
-            hipLaunchKernelGGL((gemm_bf16_dma_kernel<true, true>), grid, dim3(256), ldsz, stream, p);
+        // specialised epilogue when the launch belongs to a class and every view allows 16-B accesses (SMX_TR1_EPI=0: off)
+        static const bool fast_ok = !(getenv("SMX_TR1_EPI") && getenv("SMX_TR1_EPI")[0] == '0');
+        int epi = (fast_ok && p.atomic != 1 && smx_epi_views_aligned(p)) ? pp_epi_class(p) : -1;
+#define TR1_GO(AR, BR, E) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AR, BR, E>), grid, dim3(256), ldsz, stream, p)
+        // instantiated for the (layout, class) pairs the model launches: forward LINEAR / ACT, data gradient LINEAR / ACTGRAD,
+        // weight gradient F32
+        if (!p.a_rc && !p.b_rc) {
+            if (epi == PP_EPI_LINEAR) TR1_GO(false, false, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACT) TR1_GO(false, false, PP_EPI_ACT);
+            else TR1_GO(false, false, -1);
+        } else if (!p.a_rc && p.b_rc) {
+            if (epi == PP_EPI_LINEAR) TR1_GO(false, true, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACTGRAD) TR1_GO(false, true, PP_EPI_ACTGRAD);
+            else TR1_GO(false, true, -1);
+        } else if (p.a_rc && !p.b_rc) {
+            TR1_GO(true, false, -1);
+        } else {
+            if (epi == PP_EPI_F32) TR1_GO(true, true, PP_EPI_F32);
+            else TR1_GO(true, true, -1);
+        }
+#undef TR1_GO
         SMX_CHECK_LAUNCH();
     }
     if (p.tr_mode == 2) p.tr_mode = 1;   // register-staged kernel with transposing reads

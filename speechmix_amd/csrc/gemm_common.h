@@ -253,3 +253,22 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
     }
 }
 
+// Epilogue classes with compile-time specialised code paths (everything else takes the generic row epilogue):
+//   LINEAR: bias, dropout, residual -> bf16      ACT: bias, pre-activation copy, activation, dropout -> bf16
+//   ACTGRAD: * act'(aux_in), forward dropout mask -> bf16      F32: alpha * acc + bias -> fp32 (plain or read-modify-write)
+enum { PP_EPI_LINEAR = 0, PP_EPI_ACT = 1, PP_EPI_ACTGRAD = 2, PP_EPI_F32 = 3 };
+// epilogue class of a parameter block, or -1 when only the generic epilogue applies
+static inline int pp_epi_class(const SmxGemmParams& p) {
+    if (p.out_f32) return (p.aux_in || p.aux_out || p.resid || p.act || p.drop_p > 0.f) ? -1 : PP_EPI_F32;
+    if (p.atomic) return -1;
+    if (p.aux_in) return (p.resid || p.aux_out) ? -1 : PP_EPI_ACTGRAD;
+    if (p.act || p.aux_out) return p.resid ? -1 : PP_EPI_ACT;
+    return PP_EPI_LINEAR;
+}
+
+// the specialised epilogues use 16-B accesses on every view: all strides / offsets multiples of 8 elements, N % 8 == 0
+static inline bool smx_epi_views_aligned(const SmxGemmParams& p) {
+    const long long m = p.c.ld | p.c.off | p.c.batch_stride | p.e.ld | p.e.off | p.e.batch_stride | p.batch_c | p.batch_e |
+                        p.split_stride | p.batch_bias;
+    return !(m & 7) && !(p.N & 7);
+}

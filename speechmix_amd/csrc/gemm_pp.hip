@@ -414,7 +414,6 @@ __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[8][4], int mw0, int n
 //   EPI 3 "f32":     C(fp32) = pre [+ C when atomic == 2]                            (weight gradients, split-K slabs)
 // Side inputs of 8 row pieces are loaded together BEFORE the first store of the group: hipcc waits for its own loads with
 // counts that do not know about the inline-asm stores, so a load issued behind a store would wait for that store too.
-enum { PP_EPI_LINEAR = 0, PP_EPI_ACT = 1, PP_EPI_ACTGRAD = 2, PP_EPI_F32 = 3 };
 
 __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
     const long long m = p.c.ld | p.c.off | p.c.batch_stride | p.e.ld | p.e.off | p.e.batch_stride | p.batch_c | p.batch_e |
@@ -642,15 +641,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-}
-
-// epilogue class of a parameter block, or -1 when only the generic epilogue applies
-static int pp_epi_class(const SmxGemmParams& p) {
-    if (p.out_f32) return (p.aux_in || p.aux_out || p.resid || p.act || p.drop_p > 0.f) ? -1 : PP_EPI_F32;
-    if (p.atomic) return -1;
-    if (p.aux_in) return (p.resid || p.aux_out) ? -1 : PP_EPI_ACTGRAD;
-    if (p.act || p.aux_out) return p.resid ? -1 : PP_EPI_ACT;
-    return PP_EPI_LINEAR;
 }
 
 template <bool A_RC, bool B_RC, int EPI, bool BVIEW = false>

@@ -3,13 +3,15 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "../../speechmix_amd/csrc/gemm_common.h"
 typedef int (*gemm_fn)(const SmxGemmParams*, int, hipStream_t);
 int main(int argc, char** argv) {
     void* h = dlopen(argv[1], RTLD_NOW);
     if (!h) { printf("dlopen failed: %s\n", dlerror()); return 1; }
     gemm_fn gemm = (gemm_fn)dlsym(h, "smx_gemm");
-    const int M = 1024, N = 768;
+    const int M = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 768;
+    printf("M=%d N=%d\n", M, N);
     void *A, *B, *C;
     hipMalloc(&A, (size_t)M * 4096 * 2); hipMalloc(&B, (size_t)N * 4096 * 2); hipMalloc(&C, (size_t)M * N * 4);
     hipMemset(A, 0, (size_t)M * 4096 * 2); hipMemset(B, 0, (size_t)N * 4096 * 2);
@@ -24,10 +26,10 @@ int main(int argc, char** argv) {
             hipStreamSynchronize(st);
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0, st);
-            for (int i = 0; i < 1000; ++i) gemm(&p, 1, st);
+            for (int i = 0; i < 200; ++i) gemm(&p, 1, st);
             hipEventRecord(e1, st); hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            printf("K=%4d %s: %.2f us/launch\n", K, lab == 0 ? "full        " : lab == 0xdead0001u ? "return at top" : "no epilogue ", ms);
+            printf("K=%4d %s: %.2f us/launch\n", K, lab == 0 ? "full        " : lab == 0xdead0001u ? "return at top" : "no epilogue ", ms * 5.0f);
         }
     }
     return 0;
