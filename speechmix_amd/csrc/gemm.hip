@@ -302,6 +302,10 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
     const bool has_aux = EPI == PP_EPI_ACT && p.aux_out;
+    // (the ACT class has no register to spare for the second addressing form: it keeps view_off)
+    const bool c_plain = EPI != PP_EPI_ACT && p.c.rows_per_batch <= 0, e_plain = EPI != PP_EPI_ACT && p.e.rows_per_batch <= 0;
+    const bool need_e = EPI == PP_EPI_ACTGRAD || EPI == PP_EPI_ACT || has_res;
+    const smx_f2 al2 = SMX_PK(p.alpha);
     constexpr int QB = (EPI == PP_EPI_ACT || EPI == PP_EPI_ACTGRAD) ? 1 : 2;         // row visits per batch: what fits beside the 64 accumulator registers
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -324,8 +328,9 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                 const int lr = (q0 + qi) * 8 + rr, m = mw0 + h * 32 + lr;
                 ok[qi] = nok && m < p.M;
                 const int mm = ok[qi] ? m : 0;
-                cb[qi] = zc + view_off(p.c, mm) + n;
-                eb[qi] = EPI == PP_EPI_F32 ? 0 : ze + view_off(p.e, mm) + n;
+                // plain row views (the usual case, wave-uniform test): one 64-bit multiply-add instead of the batched-view decode
+                cb[qi] = zc + n + (c_plain ? p.c.off + (long long)mm * p.c.ld : view_off(p.c, mm));
+                eb[qi] = !need_e ? 0 : ze + n + (e_plain ? p.e.off + (long long)mm * p.e.ld : view_off(p.e, mm));
                 if (EPI == PP_EPI_ACTGRAD) {
                     side[qi] = ok[qi] ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + eb[qi]) : make_uint4(0, 0, 0, 0);
                 } else if (EPI == PP_EPI_LINEAR) {
@@ -347,8 +352,17 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
             for (int qi = 0; qi < QB; ++qi) {
                 const int m = mw0 + h * 32 + (q0 + qi) * 8 + rr;
                 float x[8] = {lo[qi][0], lo[qi][1], lo[qi][2], lo[qi][3], hi[qi][0], hi[qi][1], hi[qi][2], hi[qi][3]};
+                if constexpr (EPI == PP_EPI_ACT) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[e]);
+                    for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {          // packed fp32: two columns per instruction
+                        const smx_f2 r = __builtin_elementwise_fma((smx_f2){x[e], x[e + 1]}, al2, (smx_f2){bs[e], bs[e + 1]});
+                        x[e] = r[0];
+                        x[e + 1] = r[1];
+                    }
+                }
                 if (EPI == PP_EPI_F32) {
                     x[0] += old[qi][0].x; x[1] += old[qi][0].y; x[2] += old[qi][0].z; x[3] += old[qi][0].w;
                     x[4] += old[qi][1].x; x[5] += old[qi][1].y; x[6] += old[qi][1].z; x[7] += old[qi][1].w;
@@ -373,7 +387,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                     act_grad_mul8(x, s, p.act);
                 }
                 if (drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
-                if (EPI == PP_EPI_LINEAR) {                 // (zeros when there is no residual)
+                if (EPI == PP_EPI_LINEAR && has_res) {
                     const uint4 u = side[qi];
                     x[0] += __uint_as_float(u.x << 16); x[1] += __uint_as_float(u.x & 0xffff0000u);
                     x[2] += __uint_as_float(u.y << 16); x[3] += __uint_as_float(u.y & 0xffff0000u);
