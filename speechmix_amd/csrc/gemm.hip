@@ -304,9 +304,24 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
     const bool has_aux = EPI == PP_EPI_ACT && p.aux_out;
     // (the ACT class has no register to spare for the second addressing form: it keeps view_off)
     const bool c_plain = EPI != PP_EPI_ACT && p.c.rows_per_batch <= 0, e_plain = EPI != PP_EPI_ACT && p.e.rows_per_batch <= 0;
-    const bool need_e = EPI == PP_EPI_ACTGRAD || EPI == PP_EPI_ACT || has_res;
+    const bool need_e = EPI == PP_EPI_ACT;          // (side rows compute their own offsets in side_load)
     const smx_f2 al2 = SMX_PK(p.alpha);
-    constexpr int QB = (EPI == PP_EPI_ACT || EPI == PP_EPI_ACTGRAD) ? 1 : 2;         // row visits per batch: what fits beside the 64 accumulator registers
+    constexpr int QB = EPI == PP_EPI_F32 ? 2 : 1;         // row visits per batch: what fits beside the 64 accumulator registers
+    // residual / pre-activation rows are requested one batch AHEAD of their use (across the two halves too), so their
+    // latency sits behind the previous batch's arithmetic and the LDS round trip instead of in front of every row visit
+    constexpr bool SIDE = EPI == PP_EPI_ACTGRAD || EPI == PP_EPI_LINEAR;
+    auto side_load = [&](int hh, int q) -> uint4 {
+        const int m = mw0 + hh * 32 + q * 8 + rr;
+        const bool okk = nok && m < p.M && (EPI == PP_EPI_ACTGRAD || has_res);
+        if (!okk) return make_uint4(0, 0, 0, 0);
+        const long long e = ze + n + (e_plain ? p.e.off + (long long)m * p.e.ld : view_off(p.e, m));
+        return *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(EPI == PP_EPI_ACTGRAD ? p.aux_in : p.resid) + e);
+    };
+    uint4 side_nxt[QB];
+    if constexpr (SIDE) {
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) side_nxt[qi] = side_load(0, qi);
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -331,11 +346,8 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                 // plain row views (the usual case, wave-uniform test): one 64-bit multiply-add instead of the batched-view decode
                 cb[qi] = zc + n + (c_plain ? p.c.off + (long long)mm * p.c.ld : view_off(p.c, mm));
                 eb[qi] = !need_e ? 0 : ze + n + (e_plain ? p.e.off + (long long)mm * p.e.ld : view_off(p.e, mm));
-                if (EPI == PP_EPI_ACTGRAD) {
-                    side[qi] = ok[qi] ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + eb[qi]) : make_uint4(0, 0, 0, 0);
-                } else if (EPI == PP_EPI_LINEAR) {
-                    side[qi] = (has_res && ok[qi]) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + eb[qi])
-                                                   : make_uint4(0, 0, 0, 0);
+                if constexpr (SIDE) {
+                    side[qi] = side_nxt[qi];
                 } else if (EPI == PP_EPI_F32) {
                     if (has_acc && ok[qi]) {
                         const float* c = reinterpret_cast<const float*>(p.C) + cb[qi];
@@ -347,6 +359,14 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                 }
                 lo[qi] = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc) ^ (lr & 15)) << 4));
                 hi[qi] = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc + 1) ^ (lr & 15)) << 4));
+            }
+            if constexpr (SIDE) {
+                constexpr int NB = 4 / QB;                               // batches per half
+                const int b1 = h * NB + q0 / QB + 1;                     // (compile-time after unrolling)
+                if (b1 < 2 * NB) {
+#pragma unroll
+                    for (int qi = 0; qi < QB; ++qi) side_nxt[qi] = side_load(b1 / NB, (b1 % NB) * QB + qi);
+                }
             }
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) {
