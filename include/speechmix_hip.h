@@ -54,9 +54,11 @@ typedef struct SmxNormParams {
 typedef struct SmxNormBwdParams {
     const void *dy, *x, *dres; void* dx; const float *gamma, *beta, *mean, *rstd; float *dgamma, *dbeta, *dpos, *partials;
     int M, D, pos_period, pos_offset, rms, act; float drop_p; unsigned drop_seed;
+    int defer_fold;   /* 1: leave the gamma/beta partial rows (smx_norm_bwd_partial_rows(M) x [2][D] floats) in `partials` for smx_fold_many */
 } SmxNormBwdParams;
 int smx_norm_fwd(const SmxNormParams* p, int dtype, hipStream_t stream);
 int smx_norm_bwd(const SmxNormBwdParams* p, int dtype, hipStream_t stream);
+int smx_norm_bwd_partial_rows(int M);
 
 /* softmax(Q K^T * scale + bias [+causal]) V and its backward (dQ, dK, dV), Q/K/V/O addressed inside fused
  * projection buffers.  TF:models/wav2vec2/modeling_wav2vec2.py:466-548; TF:models/bart/modeling_bart.py:133-257;
@@ -106,6 +108,19 @@ long long smx_colsum_ws_floats(int M, int N);
 int smx_dropout_colsum(const void* x, void* out, int M, int N, float p, unsigned seed, float* colsum, float alpha, float* ws,
                        int dtype, hipStream_t stream);
 int smx_colsum_ws(const void* x, float* out, int M, int N, long long ld, float alpha, int dtype, float* ws, hipStream_t stream);
+/* Deferred second stages: with out / colsum == NULL the two launchers above leave smx_colsum_slices(M, N) (resp.
+ * smx_dropout_colsum_slices) partial rows of ceil8(N) (resp. N) floats in ws; smx_fold_many then performs up to
+ * SMX_FOLD_MAX such reductions, dst[c] += alpha * sum_r ws[r * ld + c], in one launch (the engine flushes its queue at
+ * the end of every backward stage).  smx_colsum_ws takes the two-stage path only for M >= smx_colsum_min_rows(), N % 8 == 0. */
+#define SMX_FOLD_MAX 48
+typedef struct SmxFoldEntry { const float* ws; float* dst; int nrows, ncols; long long ld; float alpha; int pad; } SmxFoldEntry;
+typedef struct SmxFoldTable { int n, pad; SmxFoldEntry e[SMX_FOLD_MAX]; } SmxFoldTable;
+int smx_fold_many(const SmxFoldTable* t, hipStream_t stream);
+int smx_colsum_slices(int M, int N);
+int smx_dropout_colsum_slices(int M, int N);
+int smx_colsum_min_rows(void);
+int smx_fold_max(void);
+int smx_sizeof_SmxFoldTable(void);
 int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream);
 int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k, int dtype, hipStream_t stream);

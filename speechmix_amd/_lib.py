@@ -63,7 +63,19 @@ class NormBwdParams(C.Structure):
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dpos", C.c_void_p), ("partials", C.c_void_p),
                 ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
-                ("rms", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint)]
+                ("rms", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint), ("defer_fold", C.c_int)]
+
+
+FOLD_MAX = 48
+
+
+class FoldEntry(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dst", C.c_void_p), ("nrows", C.c_int), ("ncols", C.c_int), ("ld", C.c_longlong),
+                ("alpha", C.c_float), ("pad", C.c_int)]
+
+
+class FoldTable(C.Structure):
+    _fields_ = [("n", C.c_int), ("pad", C.c_int), ("e", FoldEntry * FOLD_MAX)]
 
 
 class AttnParams(C.Structure):

@@ -272,9 +272,75 @@ extern "C" int smx_colsum_ws(const void* x, float* out, int M, int N, long long 
     if (dtype == SMX_BF16) hipLaunchKernelGGL(colsum_part_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, ws, M, N, ld, Np);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(colsum_part_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, ws, M, N, ld, Np);
     else return SMX_EINVAL;
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, out, gy, N, Np, alpha);
+    // out == null: the caller folds the partial rows later (smx_fold_many): smx_colsum_slices(M, N) rows of ceil8(N) floats
+    if (out) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, out, gy, N, Np, alpha);
     SMX_CHECK_LAUNCH();
 }
+extern "C" int smx_colsum_slices(int M, int N) { return colsum_slices(M, N); }
+extern "C" int smx_colsum_min_rows(void) { return SMX_COLSUM_MINM; }
+
+// Many second-stage column reductions in ONE launch: dst[c] += alpha * sum_r ws[r * ld + c] for every table entry.
+// The two-stage reductions of backward (bias gradients, LayerNorm gamma / beta gradients) each used to end in their own
+// 8-us launch of a few workgroups (~140 per step); the engine now queues them and folds a whole stage's worth at its end.
+// Entries with many partial rows are cut into row slices that add with fp32 atomics (as the LayerNorm finaliser did).
+#define SMX_FOLD_MAX 48
+struct SmxFoldEntry {
+    const float* ws;
+    float* dst;
+    int nrows, ncols;
+    long long ld;
+    float alpha;
+    int pad;
+};
+struct SmxFoldTable {
+    int n, pad;
+    SmxFoldEntry e[SMX_FOLD_MAX];
+};
+#define FOLD_ROWS_PER_SLICE 64
+__global__ __launch_bounds__(256) void fold_many_kernel(SmxFoldTable t) {
+    __shared__ float red[4][64];
+    const SmxFoldEntry& en = t.e[blockIdx.y];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.z * FOLD_ROWS_PER_SLICE, r1 = min(en.nrows, r0 + FOLD_ROWS_PER_SLICE);
+    if (blockIdx.x * 64 >= en.ncols || r0 >= en.nrows) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < en.ncols) {
+        const float* src = en.ws + c;
+        int r = r0 + w;
+        for (; r + 12 < r1; r += 16) {                 // four independent loads in flight per thread
+            a0 += src[(long long)r * en.ld];
+            a1 += src[(long long)(r + 4) * en.ld];
+            a2 += src[(long long)(r + 8) * en.ld];
+            a3 += src[(long long)(r + 12) * en.ld];
+        }
+        for (; r < r1; r += 4) a0 += src[(long long)r * en.ld];
+    }
+    red[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && c < en.ncols) {
+        const float v = en.alpha * (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+        atomicAdd(en.dst + c, v);      // (one adder per address unless the entry has several row slices or two entries share a
+                                       // destination: deterministic in the common case, never a lost update)
+    }
+}
+extern "C" int smx_fold_many(const SmxFoldTable* tp, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!tp || tp->n < 0 || tp->n > SMX_FOLD_MAX) return SMX_EINVAL;
+    if (tp->n == 0) return SMX_OK;
+    int maxc = 0, maxr = 0;
+    for (int i = 0; i < tp->n; ++i) {
+        const SmxFoldEntry& e = tp->e[i];
+        if (!e.ws || !e.dst || e.nrows <= 0 || e.ncols <= 0 || e.ld < e.ncols) return SMX_EINVAL;
+        maxc = max(maxc, e.ncols);
+        maxr = max(maxr, e.nrows);
+    }
+    dim3 grid((maxc + 63) / 64, tp->n, (maxr + FOLD_ROWS_PER_SLICE - 1) / FOLD_ROWS_PER_SLICE);
+    hipLaunchKernelGGL(fold_many_kernel, grid, dim3(256), 0, stream, *tp);
+    SMX_CHECK_LAUNCH();
+}
+extern "C" int smx_sizeof_SmxFoldTable(void) { return (int)sizeof(SmxFoldTable); }
+extern "C" int smx_fold_max(void) { return SMX_FOLD_MAX; }
 
 // ---------------------------------------------------------------- cross entropy over the vocabulary
 // CrossEntropyLoss(ignore_index=-100, mean)  (TF:models/bart/modeling_bart.py:942-946) fused with
@@ -738,18 +804,23 @@ __global__ __launch_bounds__(256) void dropout_colsum_kernel(const T* __restrict
     }
 }
 // ws: >= smx_colsum_ws_floats(M, N) floats.  colsum[n] += alpha * sum_m out[m, n]
+extern "C" int smx_dropout_colsum_slices(int M, int N) {
+    int gy = colsum_slices(M, N);
+    if (gy < 64 && M >= 4096) gy = 64;
+    return gy;
+}
 extern "C" int smx_dropout_colsum(const void* x, void* out, int M, int N, float p, unsigned seed, float* colsum, float alpha,
                                   float* ws, int dtype, hipStream_t stream) {
     (void)hipGetLastError();
-    if (M <= 0 || N <= 0 || (N & 7) || p < 0.f || p >= 1.f || !ws || !colsum) return SMX_EINVAL;
+    if (M <= 0 || N <= 0 || (N & 7) || p < 0.f || p >= 1.f || !ws) return SMX_EINVAL;
     const int gx = (N + 511) / 512, Np = N;
-    int gy = colsum_slices(M, N);
-    if (gy < 64 && M >= 4096) gy = 64;
+    const int gy = smx_dropout_colsum_slices(M, N);
     dim3 grid(gx, gy);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(dropout_colsum_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, ws, M, N, Np, p, seed);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(dropout_colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)out, ws, M, N, Np, p, seed);
     else return SMX_EINVAL;
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, colsum, gy, N, Np, alpha);
+    // colsum == null: the caller folds the gy partial rows of N floats later (smx_fold_many)
+    if (colsum) hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, ws, colsum, gy, N, Np, alpha);
     SMX_CHECK_LAUNCH();
 }
 

@@ -118,6 +118,8 @@ struct SmxNormBwdParams {
     int rms, act;
     float drop_p;         // the forward output was dropped: dy is multiplied by the same mask on load
     unsigned drop_seed;
+    int defer_fold;       // 1: leave the gamma / beta partial rows in `partials` (smx_norm_bwd_partial_rows(M) rows of
+                          // [2][D] floats); the caller reduces them into dgamma / dbeta later (smx_fold_many)
 };
 
 // Backward is two kernels: (1) dx, one wave per row at full occupancy (like the forward); (2) the gamma/beta
@@ -311,11 +313,14 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
             if (act) hipLaunchKernelGGL((norm_bwd_param_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((norm_bwd_param_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
         }
-        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((p.D + 63) / 64, blocks >= 64 ? 32 : 1), dim3(64), 0, stream,
-                           p.partials, blocks, p.D, p.dgamma, p.dbeta);
+        if (!p.defer_fold)
+            hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((p.D + 63) / 64, blocks >= 64 ? 32 : 1), dim3(64), 0, stream,
+                               p.partials, blocks, p.D, p.dgamma, p.dbeta);
     }
     SMX_CHECK_LAUNCH();
 }
+
+extern "C" int smx_norm_bwd_partial_rows(int M) { return (M + 4 * LN_PR - 1) / (4 * LN_PR); }
 
 // ABI self-description (checked by the ctypes binding against its struct mirrors)
 extern "C" int smx_sizeof_SmxNormParams(void) { return (int)sizeof(SmxNormParams); }

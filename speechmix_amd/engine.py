@@ -70,10 +70,20 @@ class Engine:
         if drop is None or N <= 0 or (N & 7) or os.environ.get("SMX_FUSE_DROPCOL") == "0":       # (env: A/B switch)
             return self._dropped(dy, drop, n), False
         out = torch.empty_like(dy)
-        ops.dropout_colsum(dy, out, n // N, N, drop[0], drop[1], bias_grad, self.dt)
+        ops.dropout_colsum(dy, out, n // N, N, drop[0], drop[1], bias_grad, self.dt, folds=self.folds)
         return out, True
 
+    @property
+    def folds(self):
+        """Queue of deferred second-stage reductions (ops.FoldQueue), or None with SMX_DEFER_FOLDS=0 (A/B switch)."""
+        f = getattr(self, "_folds", False)
+        if f is False:
+            f = self._folds = None if os.environ.get("SMX_DEFER_FOLDS") == "0" else ops.FoldQueue()
+        return f
+
     def _stage(self, name):
+        if self.folds is not None:
+            self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
         if self.stage_cb is not None:
             self.stage_cb(name)
 
@@ -216,7 +226,7 @@ class Engine:
         bv = xv if xv is not None else view(K)
         self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
         if gb is not None:
-            ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha)
+            ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
 
     def ln_fwd(self, x, wname, bname, M, D, eps, rms=False, act=ACT_NONE, pos=None, pos_period=0, pos_offset=0,
                want_sum=False, drop=None):
@@ -235,7 +245,8 @@ class Engine:
         train = self.tr(wname)
         ops.norm_bwd(dy, x, dx, self.P(wname), self.P(bname) if bname else None, mean, rstd,
                      self.G(wname) if train else None, self.G(bname) if (bname and train) else None, M, D, self.dt,
-                     rms=rms, act=act, dres=dres, dpos=dpos, pos_period=pos_period, pos_offset=pos_offset, drop=drop)
+                     rms=rms, act=act, dres=dres, dpos=dpos, pos_period=pos_period, pos_offset=pos_offset, drop=drop,
+                     folds=self.folds)
         return dx
 
     # ------------------------------------------------------------------ attention block (self or cross)
@@ -539,7 +550,7 @@ class Engine:
                 self.wgrad(dpre, x, dwp, B * To, Co, k * Cin, dyv=padv, xv=xv)
                 ops.unpack_conv_dw(dwp, self.G(p + "conv.weight"), Co, Cin, k)
                 if ec.conv_bias:
-                    ops.colsum(dpre, self.G(p + "conv.bias"), B * Tp, Co, Co, self.dt)
+                    ops.colsum(dpre, self.G(p + "conv.bias"), B * Tp, Co, Co, self.dt, folds=self.folds)
             # data gradient: one GEMM per residue r of the input position modulo the stride
             if i - 1 >= 1 and group:
                 Tpp = Tin + 2 * PAD
@@ -616,7 +627,7 @@ class Engine:
         ops.act_bwd(ds, sv["pre"], dpre, B * T, d, view(d), ACT_GELU, self.dt)
         v_n, g_n = pre_n + "parametrizations.weight.original1", pre_n + "parametrizations.weight.original0"
         if self.tr(v_n, g_n, pre_n + "bias"):
-            ops.colsum(dpre, self.G(pre_n + "bias"), B * T, d, d, self.dt)
+            ops.colsum(dpre, self.G(pre_n + "bias"), B * T, d, d, self.dt, folds=self.folds)
             n = G * Cg * K * Cg
             dwp = self.new(n, dt=torch.float32)
             split = self._split(Cg, K * Cg * G, B * T)
@@ -1206,8 +1217,12 @@ class Engine:
         ops.IN_BACKWARD = True           # kernel choice: see ops.PP_CONCURRENT_BACKWARD_OK
         try:
             self._backward(gscale, zero_grads)
+            if self.folds is not None:
+                self.folds.flush()       # anything queued after the last reported stage
         finally:
             ops.IN_BACKWARD = False
+            if self.folds is not None:
+                self.folds.items.clear()
 
     def _backward(self, gscale, zero_grads):
         sv = self.saved

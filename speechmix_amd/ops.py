@@ -235,19 +235,57 @@ def norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dtype, eps=1e-5, rms=False, ac
     L.check(L.lib().smx_norm_fwd(C.byref(p), dtype, _stream()), "smx_norm_fwd")
 
 
+class FoldQueue:
+    """Deferred second stages of the two-stage column reductions of backward (bias gradients, LayerNorm gamma / beta
+    gradients): every site leaves its partial rows in a scratch tensor and queues (scratch, rows, columns, destination);
+    `flush` reduces the whole queue in one launch per 48 entries (smx_fold_many) instead of one 8-us launch per site.
+    The engine flushes at the end of every backward stage, before that stage's gradients are handed to the reducer."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, ws, ws_off, dst, nrows, ncols, ld, alpha=1.0):
+        self.items.append((ws, ws_off, dst, nrows, ncols, ld, alpha))      # holds `ws` alive until the flush is enqueued
+
+    def flush(self):
+        items, self.items = self.items, []
+        for i in range(0, len(items), L.FOLD_MAX):
+            chunk = items[i:i + L.FOLD_MAX]
+            t = L.FoldTable()
+            t.n = len(chunk)
+            for j, (ws, off, dst, nrows, ncols, ld, alpha) in enumerate(chunk):
+                e = t.e[j]
+                e.ws, e.dst = _ptr(ws) + 4 * off, _ptr(dst)
+                e.nrows, e.ncols, e.ld, e.alpha = nrows, ncols, ld, alpha
+            L.check(L.lib().smx_fold_many(C.byref(t), _stream()), "smx_fold_many")
+
+
 def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms=False, act=ACT_NONE, dres=None,
-             dpos=None, pos_period=0, pos_offset=0, drop=None):
+             dpos=None, pos_period=0, pos_offset=0, drop=None, folds=None):
+    """folds: a FoldQueue - the gamma / beta partial rows are then reduced at its next flush instead of by a launch here."""
     ws = None
+    rows = (M + 15) // 16
     if dgamma is not None or dbeta is not None:
-        need = ((M + 15) // 16) * 2 * D
-        ws = _NORM_WS.get(dy.device)
-        if ws is None or ws.numel() < need:
-            ws = _NORM_WS[dy.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=dy.device)
+        need = rows * 2 * D
+        if folds is not None:
+            ws = torch.empty(need, dtype=torch.float32, device=dy.device)
+        else:
+            ws = _NORM_WS.get(dy.device)
+            if ws is None or ws.numel() < need:
+                ws = _NORM_WS[dy.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=dy.device)
     p = L.NormBwdParams(_ptr(dy), _ptr(x), _ptr(dres), _ptr(dx), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                         _ptr(dgamma), _ptr(dbeta), _ptr(dpos), _ptr(ws), M, D, pos_period, pos_offset, int(rms), act)
     if drop is not None and drop[0] > 0:
         p.drop_p, p.drop_seed = drop
+    if folds is not None and ws is not None:
+        p.defer_fold = 1
     L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
+    if folds is not None and ws is not None:
+        assert rows == L.lib().smx_norm_bwd_partial_rows(M)
+        if dgamma is not None:
+            folds.add(ws, 0, dgamma, rows, D, 2 * D)
+        if dbeta is not None:
+            folds.add(ws, D, dbeta, rows, D, 2 * D)
 
 
 _NORM_WS = {}
@@ -339,11 +377,19 @@ def embed_bwd(ids, dy, dtable, M, D, scale, dtype):
                                   C.c_float(scale), dtype, _stream()), "smx_embed_bwd")
 
 
-def colsum(x, out, M, N, ld, dtype, alpha=1.0):
-    """out[n] += alpha * sum_m x[m, n]; tall inputs go through the two-stage kernel with a cached scratch buffer."""
+def colsum(x, out, M, N, ld, dtype, alpha=1.0, folds=None):
+    """out[n] += alpha * sum_m x[m, n]; tall inputs go through the two-stage kernel with a cached scratch buffer, or -
+    with a FoldQueue - leave their partial rows for its next flush."""
     fn = L.lib().smx_colsum_ws_floats
     fn.restype = C.c_longlong
     need = int(fn(M, N))
+    if (folds is not None and M >= L.lib().smx_colsum_min_rows() and N % 8 == 0 and ld % 8 == 0
+            and os.environ.get("SMX_COLSUM") != "atomic"):
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+        L.check(L.lib().smx_colsum_ws(C.c_void_p(_ptr(x)), C.c_void_p(0), M, N, C.c_longlong(ld), C.c_float(alpha),
+                                      dtype, C.c_void_p(_ptr(ws)), _stream()), "smx_colsum_ws")
+        folds.add(ws, 0, out, L.lib().smx_colsum_slices(M, N), N, (N + 7) // 8 * 8, alpha)
+        return
     ws = _COLSUM_WS.get(x.device)
     if os.environ.get("SMX_COLSUM") == "atomic":          # A/B switch: single-stage atomic kernel
         L.check(L.lib().smx_colsum(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_longlong(ld), C.c_float(alpha),
@@ -358,11 +404,20 @@ def colsum(x, out, M, N, ld, dtype, alpha=1.0):
 _COLSUM_WS = {}
 
 
-def dropout_colsum(x, out, M, N, p, seed, colsum_out, dtype, alpha=1.0):
-    """out = dropout(x; p, seed) and colsum_out[n] += alpha * sum_m out[m, n] in one pass (N % 8 == 0)."""
+def dropout_colsum(x, out, M, N, p, seed, colsum_out, dtype, alpha=1.0, folds=None):
+    """out = dropout(x; p, seed) and colsum_out[n] += alpha * sum_m out[m, n] in one pass (N % 8 == 0); with a FoldQueue
+    the column sums land at its next flush."""
     fn = L.lib().smx_colsum_ws_floats
     fn.restype = C.c_longlong
     need = max(int(fn(M, N)), 64 * N)
+    if folds is not None:
+        slices = L.lib().smx_dropout_colsum_slices(M, N)
+        ws = torch.empty(max(need, slices * N), dtype=torch.float32, device=x.device)
+        L.check(L.lib().smx_dropout_colsum(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, N, C.c_float(p), C.c_uint(seed),
+                                           C.c_void_p(0), C.c_float(alpha), C.c_void_p(_ptr(ws)), dtype, _stream()),
+                "smx_dropout_colsum")
+        folds.add(ws, 0, colsum_out, slices, N, N, alpha)
+        return
     ws = _COLSUM_WS.get(x.device)
     if ws is None or ws.numel() < need:
         ws = _COLSUM_WS[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=x.device)

@@ -38,8 +38,9 @@ def test_struct_layouts_match_ctypes(lib):
     for name, st in (("SmxGemmParams", L.GemmParams), ("SmxNormParams", L.NormParams), ("SmxNormBwdParams", L.NormBwdParams),
                      ("SmxAttnParams", L.AttnParams), ("SmxConv0Params", L.Conv0Params), ("SmxCEParams", L.CEParams),
                      ("SmxOptParams", L.OptParams), ("SmxWsumParams", L.WsumParams), ("SmxAfParams", L.AfParams),
-                     ("SmxAfTensor", L.AfTensor), ("SmxAfTile", L.AfTile)):
+                     ("SmxAfTensor", L.AfTensor), ("SmxAfTile", L.AfTile), ("SmxFoldTable", L.FoldTable)):
         assert getattr(lib, "smx_sizeof_" + name)() == C.sizeof(st), name
+    assert lib.smx_fold_max() == L.FOLD_MAX
 
 
 def test_header_is_plain_c_and_agrees_with_library(lib, tmp_path):

@@ -139,3 +139,59 @@ def test_native_step_runner_trains_and_matches_autograd_path():
     for _ in range(8):
         last = runner2.step(inp["input_values"], inp["labels"]).item()
     assert last < first - 0.1
+
+
+def test_deferred_folds_equal_the_immediate_second_stages():
+    """smx_fold_many against torch, and the queued forms of colsum / dropout_colsum / norm_bwd against their immediate forms."""
+    import torch
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    # (1) the fold kernel itself: short and long entries, a row offset inside the scratch, alpha, a shared destination
+    q = ops.FoldQueue()
+    ws1 = torch.randn(40, 776, device=dev); d1 = torch.randn(768, device=dev); r1 = d1 + 0.5 * ws1[:, :768].sum(0)
+    ws2 = torch.randn(998, 2 * 512, device=dev); d2 = torch.zeros(512, device=dev); d3 = torch.zeros(512, device=dev)
+    q.add(ws1, 0, d1, 40, 768, 776, 0.5)
+    q.add(ws2, 0, d2, 998, 512, 1024)
+    q.add(ws2, 512, d3, 998, 512, 1024)
+    q.add(ws1, 0, d3, 40, 512, 776)                          # second entry on the same destination
+    q.flush()
+    assert torch.allclose(d1, r1, atol=1e-4, rtol=1e-5)
+    assert torch.allclose(d2, ws2[:, :512].sum(0), atol=2e-3, rtol=1e-4)
+    assert torch.allclose(d3, ws2[:, 512:].sum(0) + ws1[:, :512].sum(0), atol=2e-3, rtol=1e-4)
+    assert not q.items
+    # more entries than one table holds
+    outs = [torch.zeros(64, device=dev) for _ in range(60)]
+    srcs = [torch.randn(8, 64, device=dev) for _ in range(60)]
+    for s, o in zip(srcs, outs):
+        q.add(s, 0, o, 8, 64, 64)
+    q.flush()
+    assert all(torch.allclose(o, s.sum(0), atol=1e-5) for s, o in zip(srcs, outs))
+    # (2) queued == immediate at the three sites
+    M, N = 8192, 768
+    x = torch.randn(M, N, device=dev).bfloat16()
+    a, b = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    ops.colsum(x, a, M, N, N, ops.BF16)
+    ops.colsum(x, b, M, N, N, ops.BF16, folds=q)
+    assert len(q.items) == 1 and float(b.abs().max()) == 0.0
+    q.flush()
+    assert torch.allclose(a, b, atol=1e-3, rtol=1e-5)
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    a.zero_(); b.zero_()
+    ops.dropout_colsum(x, o1, M, N, 0.1, 77, a, ops.BF16)
+    ops.dropout_colsum(x, o2, M, N, 0.1, 77, b, ops.BF16, folds=q)
+    q.flush()
+    assert torch.equal(o1, o2) and torch.allclose(a, b, atol=1e-3, rtol=1e-5)
+    D = 768
+    xn = torch.randn(M, D, device=dev).bfloat16(); dy = torch.randn(M, D, device=dev).bfloat16()
+    gamma, beta = torch.randn(D, device=dev), torch.randn(D, device=dev)
+    mean, rstd = xn.float().mean(1), 1.0 / xn.float().std(1)
+    res = []
+    for folds in (None, q):
+        dx = torch.empty_like(xn); dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
+        ops.norm_bwd(dy, xn, dx, gamma, beta, mean, rstd, dg, db, M, D, ops.BF16, folds=folds)
+        if folds is not None:
+            folds.flush()
+        res.append((dx, dg, db))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], atol=5e-2, rtol=1e-4) and torch.allclose(res[0][2], res[1][2], atol=5e-2, rtol=1e-4)
