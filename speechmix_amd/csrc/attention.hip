@@ -27,12 +27,30 @@ struct SmxAttnParams {
     int B, H, Tq, Tk, D;
     int causal;
     float scale;
-    float drop_p;         // dropout on the attention probabilities (0: off); mask index = ((b*H+h)*Tq+q)*Tk+key
+    float drop_p;         // dropout on the attention probabilities (0: off); mask index = ((b*H+h)*Tq+q)*Tkp+key, Tkp = Tk rounded up to a multiple of 4
     unsigned drop_seed;
 };
+// Mask index of probability (b, h, q, key): ((b H + h) Tq + q) Tkp + key with Tkp = Tk rounded up to a multiple of 4, so
+// that the 4 consecutive keys a lane holds per 16x16 score block (first key % 4 == 0) are 4 consecutive, 4-aligned
+// indices: TWO hashes (the mask function yields two elements per hash, smx_common.h) instead of four, and one row-base
+// computation per query instead of a 64-bit index per element.  Attention dropout hashes every score; in train mode
+// that was as much vector work as the softmax itself.
+__device__ __forceinline__ unsigned att_row_base(const SmxAttnParams& p, int b, int h, int q) {
+    return (unsigned)((((long long)b * p.H + h) * p.Tq + q) * (long long)((p.Tk + 3) & ~3));
+}
 #define ATT_DROP(p, b, h, q, k) \
-    smx_drop_mul((p).drop_seed, (unsigned)((((long long)(b) * (p).H + (h)) * (p).Tq + (q)) * (p).Tk + (k)), smx_thresh24((p).drop_p), \
-                 1.0f / (1.0f - (p).drop_p))
+    smx_drop_mul((p).drop_seed, att_row_base(p, b, h, q) + (unsigned)(k), smx_thresh24((p).drop_p), 1.0f / (1.0f - (p).drop_p))
+// multipliers of keys key0 .. key0 + 3 (key0 % 4 == 0) of the row with base rb
+__device__ __forceinline__ void att_drop4(const SmxAttnParams& p, unsigned rb, int key0, float (&dm)[4]) {
+    const unsigned th = smx_thresh24(p.drop_p) >> 8;
+    const float inv = 1.0f / (1.0f - p.drop_p);
+    const unsigned i2 = (rb + (unsigned)key0) >> 1;
+    const unsigned h0 = smx_hash32(p.drop_seed, i2), h1 = smx_hash32(p.drop_seed, i2 + 1);
+    dm[0] = (h0 & 0xffffu) >= th ? inv : 0.f;
+    dm[1] = (h0 >> 16) >= th ? inv : 0.f;
+    dm[2] = (h1 & 0xffffu) >= th ? inv : 0.f;
+    dm[3] = (h1 >> 16) >= th ? inv : 0.f;
+}
 
 #define NEG_BIG (-1e30f)
 
@@ -319,14 +337,19 @@ __global__ __launch_bounds__(256, U == 1 ? 4 : 2) void attn_fwd_bf16(SmxAttnPara
             const float mn = fmaxf(m[u], mx * mul);
             const float alpha = fast_exp2(m[u] - mn);
             float rs = 0.f;
+            const bool drop = p.drop_p > 0.f;
+            const unsigned rb = drop ? att_row_base(p, b, h, q) : 0u;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop) att_drop4(p, rb, k0 + t * 16 + 4 * g, dm);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = fast_exp2(fmaf(s[u][t][r], mul, -mn));
                     rs += e;
-                    s[u][t][r] = p.drop_p > 0.f ? e * ATT_DROP(p, b, h, q, k0 + t * 16 + 4 * g + r) : e;
+                    s[u][t][r] = e * dm[r];
                 }
+            }
             l[u] = l[u] * alpha + group_sum(rs);
             m[u] = mn;
 #pragma unroll
@@ -445,6 +468,8 @@ __global__ __launch_bounds__(256, U == 1 ? 3 : 1) void attn_bwd_dq_bf16(SmxAttnP
                 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f, qf[u][1], sc, 0, 0, 0);
                 f32x4_t dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0f, dof[u][0], ZERO4, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1f, dof[u][1], dp, 0, 0, 0);
+                float dm4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop_p > 0.f) att_drop4(p, att_row_base(p, b, h, q), k0 + t * 16 + 4 * g, dm4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + t * 16 + 4 * g + r;
@@ -452,8 +477,7 @@ __global__ __launch_bounds__(256, U == 1 ? 3 : 1) void attn_bwd_dq_bf16(SmxAttnP
                     if (p.bias && q < p.Tq && key < p.Tk) off = fmaf(p.bias[((long long)h * p.Tq + q) * p.Tk + key], SMX_LOG2E, off);
                     float pr = fast_exp2(fmaf(sc[r], sl2, off));
                     if (masked && (key >= p.Tk || q >= p.Tq || (p.causal && key > q + coff))) pr = 0.f;
-                    const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, q, key) : 1.f;
-                    ds[u][t][r] = pr * (dm * dp[r] - delta[u]);
+                    ds[u][t][r] = pr * (dm4[r] * dp[r] - delta[u]);
                 }
             }
         }
@@ -571,6 +595,23 @@ __global__ __launch_bounds__(256, U == 1 ? 2 : 1) void attn_bwd_dkv_bf16(SmxAttn
                 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[u][1], sc, 0, 0, 0);
                 f32x4_t dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0f, vf[u][0], ZERO4, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1f, vf[u][1], dp, 0, 0, 0);
+                // dropout multipliers of my 4 queries x my key.  Keys 2j and 2j+1 of a row share a hash and sit in
+                // neighbouring lanes (kw0 + 16 u is even): the even lane hashes queries r = 0, 1, the odd lane r = 2, 3, and
+                // a DPP quad swap hands each its partner's pair - two hashes per lane instead of four.
+                float dm4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop_p > 0.f) {
+                    const unsigned odd = (unsigned)key & 1u, th16 = smx_thresh24(p.drop_p) >> 8;
+                    const float inv = 1.0f / (1.0f - p.drop_p);
+                    const int ra = q0 + t * 16 + 4 * g + 2 * (int)odd;
+                    const unsigned kk = (unsigned)key >> 1;
+                    const unsigned own0 = smx_hash32(p.drop_seed, (att_row_base(p, b, h, ra) >> 1) + kk);
+                    const unsigned own1 = smx_hash32(p.drop_seed, (att_row_base(p, b, h, ra + 1) >> 1) + kk);
+                    const unsigned oth0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own0, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                    const unsigned oth1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own1, 0xB1, 0xf, 0xf, true);
+                    const unsigned h4[4] = {odd ? oth0 : own0, odd ? oth1 : own1, odd ? own0 : oth0, odd ? own1 : oth1};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dm4[r] = (odd ? h4[r] >> 16 : h4[r] & 0xffffu) >= th16 ? inv : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qq = q0 + t * 16 + 4 * g + r;
@@ -578,7 +619,7 @@ __global__ __launch_bounds__(256, U == 1 ? 2 : 1) void attn_bwd_dkv_bf16(SmxAttn
                     if (p.bias && qq < p.Tq && key < p.Tk) off = fmaf(p.bias[((long long)h * p.Tq + qq) * p.Tk + key], SMX_LOG2E, off);
                     float pr = fast_exp2(fmaf(sc[r], sl2, off));
                     if (masked && (qq >= p.Tq || key >= p.Tk || (p.causal && key > qq + coff))) pr = 0.f;
-                    const float dm = p.drop_p > 0.f ? ATT_DROP(p, b, h, qq, key) : 1.f;
+                    const float dm = dm4[r];
                     pt[u][t][r] = pr * dm;
                     ds[u][t][r] = pr * (dm * dp[r] - dl[r]);
                 }

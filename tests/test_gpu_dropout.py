@@ -138,7 +138,8 @@ def test_attention_probability_dropout_matches_torch_reference(dtype, D, causal)
     desc.set("dV", dqkv, 2 * d, T * 3 * d, 3 * d)
     ops.attention_bwd(desc, lse, delta, dt)
     # torch fp32 reference with the very same mask
-    mask = _mask((B, H, T, T), p, seed, dev)
+    Tp = (T + 3) // 4 * 4                       # mask rows are indexed with the key count rounded up to a multiple of 4
+    mask = _mask((B, H, T, Tp), p, seed, dev)[..., :T]
     x = qkv.float().view(B, T, 3, H, D).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)   # [3,B,H,T,D]
     s = (x[0] @ x[1].transpose(-1, -2)) * scale
     if causal:
