@@ -283,15 +283,18 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
 // pre-activation / accumulate target) issued first, all eight LDS reads together, then the arithmetic of the class only,
 // then the stores - with no ragged-tail path and no per-visit flag tests.  The generic form spent ~3.5 us per tile here
 // (a quarter of a K = 768 launch: the workgroups of a CU reach their epilogues together and are bound by VALU issue).
-template <int EPI>
+// EPIX: class of gemm_common.h, or 4 / 5 = ACT / ACTGRAD whose side tensor is the local derivative (SMX_ACT_SAVE_GRAD)
+template <int EPIX>
 __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
                                                      long long zc, long long zbias, long long ze, int lane) {
+    constexpr int EPI = EPIX == 4 ? PP_EPI_ACT : EPIX == 5 ? PP_EPI_ACTGRAD : EPIX;
+    constexpr bool sg = EPIX >= 4;
     const int i16 = lane & 15, g = lane >> 4;
     const int rr = lane >> 3, cc = lane & 7;
     const int n = nw0 + cc * 8;
     const bool nok = n < p.N;                          // N % 8 == 0: all 8 columns or none
     float bs[8];
-    if (p.bias && nok) load8(p.bias + zbias + n, bs);
+    if (EPIX != 5 && p.bias && nok) load8(p.bias + zbias + n, bs);     // (class 5, a data gradient, is launched without a bias)
     else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[e] = 0.f;
@@ -302,6 +305,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
     const bool has_aux = EPI == PP_EPI_ACT && p.aux_out;
+    const int act = p.act & 0xff;
     // (the ACT class has no register to spare for the second addressing form: it keeps view_off)
     const bool c_plain = EPI != PP_EPI_ACT && p.c.rows_per_batch <= 0, e_plain = EPI != PP_EPI_ACT && p.e.rows_per_batch <= 0;
     const bool need_e = EPI == PP_EPI_ACT;          // (side rows compute their own offsets in side_load)
@@ -394,19 +398,34 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                     continue;
                 }
                 if (EPI == PP_EPI_ACT) {
-                    if (has_aux && ok[qi])
-                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[qi]) =
-                            make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
-                    act_fwd8(x, p.act);
+                    const unsigned didx = (unsigned)((long long)m * p.N + n + zc);
+                    if constexpr (sg) {       // side tensor = local derivative: activation, mask and derivative pair by pair
+                        const uint4 d = act_fwd_grad_drop8(x, act, drop, p.drop_seed, didx, th, inv_keep);
+                        if (has_aux && ok[qi]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[qi]) = d;
+                    } else {
+                        if (has_aux && ok[qi])
+                            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[qi]) =
+                                make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
+                        act_fwd8(x, act);
+                        if (drop) smx_drop_mul8(p.drop_seed, didx, th, inv_keep, x);
+                    }
                 }
                 if (EPI == PP_EPI_ACTGRAD) {
                     const uint4 u = side[qi];
-                    float s[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                                  __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
-                                  __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
-                    act_grad_mul8(x, s, p.act);
+                    if constexpr (sg) {
+                        x[0] *= __uint_as_float(u.x << 16); x[1] *= __uint_as_float(u.x & 0xffff0000u);
+                        x[2] *= __uint_as_float(u.y << 16); x[3] *= __uint_as_float(u.y & 0xffff0000u);
+                        x[4] *= __uint_as_float(u.z << 16); x[5] *= __uint_as_float(u.z & 0xffff0000u);
+                        x[6] *= __uint_as_float(u.w << 16); x[7] *= __uint_as_float(u.w & 0xffff0000u);
+                    } else {
+                        float s[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                      __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                      __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+                        act_grad_mul8(x, s, act);
+                        if (drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
+                    }
                 }
-                if (drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
+                if (EPI == PP_EPI_LINEAR && drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
                 if (EPI == PP_EPI_LINEAR && has_res) {
                     const uint4 u = side[qi];
                     x[0] += __uint_as_float(u.x << 16); x[1] += __uint_as_float(u.x & 0xffff0000u);
@@ -425,7 +444,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
 #ifndef TR1_MINWG
 #define TR1_MINWG 4
 #endif
-template <bool A_RC, bool B_RC, int EPI = -1>       // EPI: epilogue class (gemm_common.h) on aligned views, -1: generic
+template <bool A_RC, bool B_RC, int EPI = -1>       // EPI: epilogue class (gemm_common.h; 4 / 5: see epilogue_staged_fast) on aligned views, -1: generic
 __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.drop_seed == 0xdead0001u) return;      // LAB
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SmxGemmParams p, c
         float bs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
-        epilogue_row8(p, 0, 0, m, n, x, bs, th, inv_keep);
+        epilogue_row8<false, true>(p, 0, 0, m, n, x, bs, th, inv_keep);
     }
 }
 extern "C" int smx_gemm_splitk_epilogue(const SmxGemmParams* pp, const float* slabs, int nsplit, long long stride, int ldn,
@@ -687,12 +706,14 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     if (p.split_k > 1 && p.atomic != 1 && (p.atomic == 2 || p.split_stride <= 0)) return SMX_EINVAL;
     if (p.atomic && !(p.out_f32 || dtype == SMX_F32)) return SMX_EINVAL;
     if (dtype == SMX_F32) {
+        if (p.act & SMX_ACT_SAVE_GRAD) return SMX_EINVAL;        // bf16 kernels only
         p.out_f32 = 1;
         dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), 1, p.nbatch * p.split_k);
         hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, p);
         SMX_CHECK_LAUNCH();
     }
     if (dtype != SMX_BF16) return SMX_EINVAL;
+    if ((p.act & SMX_ACT_SAVE_GRAD) && ((p.tr_mode & 255) == 0 || (p.tr_mode & 255) == 2)) return SMX_EINVAL;   // production kernels only
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
     if ((p.tr_mode & 255) == 8) return smx_gemm_pp(p, stream);        // 256 x 256, persistent ping-pong
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
@@ -700,16 +721,23 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
         const size_t ldsz = STAGE_BYTES;
         // specialised epilogue when the launch belongs to a class and every view allows 16-B accesses (SMX_TR1_EPI=0: off)
         static const bool fast_ok = !(getenv("SMX_TR1_EPI") && getenv("SMX_TR1_EPI")[0] == '0');
-        int epi = (fast_ok && p.atomic != 1 && smx_epi_views_aligned(p)) ? pp_epi_class(p) : -1;
+        const bool flagged = (p.act & SMX_ACT_SAVE_GRAD) != 0;
+        int epi = ((fast_ok || flagged) && p.atomic != 1 && smx_epi_views_aligned(p)) ? pp_epi_class(p) : -1;
+        // saved-derivative side tensors exist in the forward ACT and the data-gradient ACTGRAD epilogues (and in the split-K
+        // epilogue kernel, whose slab-writing GEMM carries no activation)
+        if (flagged && !((!p.a_rc && !p.b_rc && epi == PP_EPI_ACT) || (!p.a_rc && p.b_rc && epi == PP_EPI_ACTGRAD))) return SMX_EINVAL;
 #define TR1_GO(AR, BR, E) hipLaunchKernelGGL((gemm_bf16_dma_kernel<AR, BR, E>), grid, dim3(256), ldsz, stream, p)
         // instantiated for the (layout, class) pairs the model launches: forward LINEAR / ACT, data gradient LINEAR / ACTGRAD,
         // weight gradient F32
         if (!p.a_rc && !p.b_rc) {
             if (epi == PP_EPI_LINEAR) TR1_GO(false, false, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACT && flagged) TR1_GO(false, false, 4);
             else if (epi == PP_EPI_ACT) TR1_GO(false, false, PP_EPI_ACT);
             else TR1_GO(false, false, -1);
         } else if (!p.a_rc && p.b_rc) {
             if (epi == PP_EPI_LINEAR) TR1_GO(false, true, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACTGRAD && flagged && !p.bias) TR1_GO(false, true, 5);
+            else if (flagged) return SMX_EINVAL;
             else if (epi == PP_EPI_ACTGRAD) TR1_GO(false, true, PP_EPI_ACTGRAD);
             else TR1_GO(false, true, -1);
         } else if (p.a_rc && !p.b_rc) {

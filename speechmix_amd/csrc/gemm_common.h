@@ -175,7 +175,9 @@ __device__ __forceinline__ void st8(float* p, const float v[8]) {
     st_b128(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
 }
 
-template <bool ASM_ST = false>
+// SG: honour SMX_ACT_SAVE_GRAD (the split-K epilogue kernel; the GEMM kernels take flagged launches only through their
+// class-specialised epilogues - the launcher checks - and keep this path's register footprint)
+template <bool ASM_ST = false, bool SG = false>
 __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long zc, long long ze, int m, int n, float x[8],
                                               const float bs[8], unsigned th, float inv_keep) {
     const long long base = zc + view_off(p.c, m) + n;
@@ -188,16 +190,27 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
     bf16_t* aux_out = reinterpret_cast<bf16_t*>(p.aux_out);
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[e]);
+    const int act = p.act & 0xff;
+    const bool sg = SG && (p.act & SMX_ACT_SAVE_GRAD) != 0;  // side tensor = local derivative (see smx_common.h)
     if (fast) {
-        if (aux_out) st8<ASM_ST>(aux_out + sb, x);
+        if (aux_out && !sg) st8<ASM_ST>(aux_out + sb, x);
+        const bool fused = sg && aux_out && !aux_in;       // forward with saved derivative: activation, mask and side store together
         if (aux_in) {
             float a[8];
             load8(aux_in + sb, a);
-            act_grad_mul8(x, a, p.act);
-        } else if (p.act) {
-            act_fwd8(x, p.act);
+            if (sg) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] *= a[e];
+            } else {
+                act_grad_mul8(x, a, act);
+            }
+        } else if (fused) {
+            const uint4 d = act_fwd_grad_drop8(x, act, p.drop_p > 0.f, p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
+            if (ASM_ST) st_b128(aux_out + sb, d); else *reinterpret_cast<uint4*>(aux_out + sb) = d;
+        } else if (act) {
+            act_fwd8(x, act);
         }
-        if (p.drop_p > 0.f) {
+        if (p.drop_p > 0.f && !sg) {
             const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
             if (!(idx & 1u)) smx_drop_mul8(p.drop_seed, idx, th, inv_keep, x);
             else
@@ -232,12 +245,14 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
     // ragged / unaligned tail (LM head with V % 8 != 0, odd views): element-wise
     for (int e = 0; e < nv; ++e) {
         float v = x[e];
+        const float mk = (p.drop_p > 0.f && !(aux_in && sg)) ? smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n + e + zc), th, inv_keep) : 1.f;
         if (aux_out) {
-            if (ASM_ST) st_b16(aux_out + sb + e, f2bf(v)); else aux_out[sb + e] = f2bf(v);
+            const float s = sg ? act_grad(v, act) * mk : v;
+            if (ASM_ST) st_b16(aux_out + sb + e, f2bf(s)); else aux_out[sb + e] = f2bf(s);
         }
-        if (aux_in) v *= act_grad(bf2f(aux_in[sb + e]), p.act);
-        else v = act_fwd(v, p.act);
-        if (p.drop_p > 0.f) v *= smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n + e + zc), th, inv_keep);
+        if (aux_in) v *= sg ? bf2f(aux_in[sb + e]) : act_grad(bf2f(aux_in[sb + e]), act);
+        else v = act_fwd(v, act);
+        v *= mk;
         if (resid) v += bf2f(resid[sb + e]);
         if (!p.out_f32) {
             if (ASM_ST) st_b16(reinterpret_cast<bf16_t*>(p.C) + base + e, f2bf(v));

@@ -139,6 +139,72 @@ __device__ __forceinline__ void act_fwd8(float x[8], int act) {
         for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
     }
 }
+// SmxGemmParams.act may carry this flag (bf16 GEMMs): the side tensor then holds the LOCAL DERIVATIVE of the epilogue,
+// d out / d pre = act'(pre) * dropout multiplier, written by the forward launch (aux_out) and multiplied in by the backward
+// launch (aux_in) - which then needs neither the erf / exp of the activation gradient nor the dropout hash.  Rounded to
+// bf16 like the pre-activation it replaces (its error, <= 2^-9 of a value in [-0.13, 1.13], is of the size the rounding of
+// the pre-activation already put on the recomputed derivative).
+#define SMX_ACT_SAVE_GRAD 0x100
+// x -> act(x), d = act'(x): one erf / exp evaluation serves both
+__device__ __forceinline__ void act_fwd_grad8(float x[8], float d[8], int act) {
+    if (act == SMX_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const smx_f2 v = {x[e], x[e + 1]};
+            smx_f2 er, E;
+            smx_erf_e2(v, er, E);
+            const smx_f2 hx = v * SMX_PK(0.5f);
+            const smx_f2 y = __builtin_elementwise_fma(hx, er, hx);
+            const smx_f2 cdf = __builtin_elementwise_fma(er, SMX_PK(0.5f), SMX_PK(0.5f));
+            const smx_f2 gr = __builtin_elementwise_fma(v * SMX_PK(0.39894228040143267794f), E, cdf);
+            x[e] = y[0]; x[e + 1] = y[1];
+            d[e] = gr[0]; d[e + 1] = gr[1];
+        }
+    } else if (act == SMX_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d[e] = x[e] > 0.f ? 1.f : 0.f; x[e] = fmaxf(x[e], 0.f); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = 1.f;
+    }
+}
+__device__ __forceinline__ unsigned smx_hash32(unsigned seed, unsigned idx);      // (dropout section below)
+// the forward epilogue of a Linear -> activation -> dropout with SMX_ACT_SAVE_GRAD, pair by pair (few live registers):
+// x -> act(x) * m, returns the bf16-packed local derivative act'(x) * m (m = dropout multiplier, 1 when drop is false);
+// idx: even mask index of x[0]
+__device__ __forceinline__ uint4 act_fwd_grad_drop8(float x[8], int act, bool drop, unsigned seed, unsigned idx, unsigned thresh24,
+                                                    float inv_keep) {
+    unsigned pk[4];
+    const unsigned th = thresh24 >> 8;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        smx_f2 y, gr;
+        const smx_f2 v = {x[e], x[e + 1]};
+        if (act == SMX_ACT_GELU) {
+            smx_f2 er, E;
+            smx_erf_e2(v, er, E);
+            const smx_f2 hx = v * SMX_PK(0.5f);
+            y = __builtin_elementwise_fma(hx, er, hx);
+            gr = __builtin_elementwise_fma(v * SMX_PK(0.39894228040143267794f), E, __builtin_elementwise_fma(er, SMX_PK(0.5f), SMX_PK(0.5f)));
+        } else if (act == SMX_ACT_RELU) {
+            y = (smx_f2){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+            gr = (smx_f2){v[0] > 0.f ? 1.f : 0.f, v[1] > 0.f ? 1.f : 0.f};
+        } else {
+            y = v;
+            gr = SMX_PK(1.f);
+        }
+        if (drop) {
+            const unsigned h = smx_hash32(seed, (idx >> 1) + (e >> 1));
+            const smx_f2 m = {(h & 0xffffu) >= th ? inv_keep : 0.f, (h >> 16) >= th ? inv_keep : 0.f};
+            y *= m;
+            gr *= m;
+        }
+        x[e] = y[0];
+        x[e + 1] = y[1];
+        pk[e >> 1] = pack_bf2(gr[0], gr[1]);
+    }
+    return make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
 // x[e] *= act'(pre[e])
 __device__ __forceinline__ void act_grad_mul8(float x[8], const float pre[8], int act) {
     if (act == SMX_ACT_GELU) {
@@ -174,6 +240,16 @@ __device__ __forceinline__ unsigned smx_hash32(unsigned seed, unsigned idx) {
 __device__ __forceinline__ float smx_drop_mul(unsigned seed, unsigned idx, unsigned thresh24, float inv_keep) {
     const unsigned h = smx_hash32(seed, idx >> 1);
     return ((idx & 1u) ? h >> 16 : h & 0xffffu) >= (thresh24 >> 8) ? inv_keep : 0.f;
+}
+// m[e] = multiplier(idx + e) for 8 consecutive elements starting at an EVEN idx: four hashes
+__device__ __forceinline__ void smx_drop_mults8(unsigned seed, unsigned idx, unsigned thresh24, float inv_keep, float m[8]) {
+    const unsigned th = thresh24 >> 8;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const unsigned h = smx_hash32(seed, (idx >> 1) + (e >> 1));
+        m[e] = (h & 0xffffu) >= th ? inv_keep : 0.f;
+        m[e + 1] = (h >> 16) >= th ? inv_keep : 0.f;
+    }
 }
 // x[e] *= multiplier(idx + e) for 8 consecutive elements starting at an EVEN idx: four hashes
 __device__ __forceinline__ void smx_drop_mul8(unsigned seed, unsigned idx, unsigned thresh24, float inv_keep, float x[8]) {

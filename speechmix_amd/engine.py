@@ -324,13 +324,17 @@ class Engine:
     def _ffn_fwd(self, h, M, d, F, n1, n2, act, resid, d_act=None, d_out=None):
         """resid + drop_out(fc2(drop_act(act(fc1(h)))))  - both dropouts run inside the GEMM epilogues."""
         pre = self.new(M, F)
+        # bf16: `pre` holds act'(fc1 out) * activation-dropout multiplier - the local derivative the backward GEMM multiplies
+        # in - instead of the pre-activation (ops.ACT_SAVE_GRAD: no erf / exp and no dropout hash in the backward epilogue)
+        if self.dt == BF16 and act != ACT_NONE and os.environ.get("SMX_SAVE_ACT_GRAD") != "0":
+            act = act | ops.ACT_SAVE_GRAD
         f = self.lin(h, self.W(n1[0]), self.P(n1[1]) if n1[1] else None, M, F, d, act=act, aux_out=pre, drop=d_act)
         y = self.lin(f, self.W(n2[0]), self.P(n2[1]) if n2[1] else None, M, d, F, resid=resid, drop=d_out)
-        return y, (h, pre, f, d_act, d_out)
+        return y, (h, pre, f, d_act, d_out, act)
 
     def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid):
         """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid)."""
-        h, pre, f, d_act, d_out = sv
+        h, pre, f, d_act, d_out, act = sv            # (act as the forward used it: may carry ACT_SAVE_GRAD)
         gb = self.G(n2[1]) if (n2[1] and self.tr(n2[0])) else None
         dy, fused = self._dropped(dy, d_out, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, d_out, M * d), False)
         if self.tr(n2[0]):

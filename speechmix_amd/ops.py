@@ -77,7 +77,12 @@ def pp_allowed():
     return PP_MODE != "0" and (PP_MODE == "1" or PP_CONCURRENT_BACKWARD_OK or not IN_BACKWARD)
 
 
+ACT_SAVE_GRAD = 0x100     # SMX_ACT_SAVE_GRAD: the GEMM's side tensor holds the epilogue's local derivative (smx_common.h)
+
+
 def _pp_applicable(p, dtype):
+    if p.act & ACT_SAVE_GRAD:
+        return False
     if dtype != BF16 or p.atomic == 1 or p.M < 256 or p.N < 64 or max(p.M, p.N, p.K) >= (1 << 22):
         return False
     if (p.K & 7) and not (p.a_rc and p.b_rc):
