@@ -284,7 +284,7 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
 // then the stores - with no ragged-tail path and no per-visit flag tests.  The generic form spent ~3.5 us per tile here
 // (a quarter of a K = 768 launch: the workgroups of a CU reach their epilogues together and are bound by VALU issue).
 // EPIX: class of gemm_common.h, or 4 / 5 = ACT / ACTGRAD whose side tensor is the local derivative (SMX_ACT_SAVE_GRAD)
-template <int EPIX>
+template <int EPIX, int QBX = 0>       // QBX: row visits per batch (0: by class)
 __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
                                                      long long zc, long long zbias, long long ze, int lane) {
     constexpr int EPI = EPIX == 4 ? PP_EPI_ACT : EPIX == 5 ? PP_EPI_ACTGRAD : EPIX;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
     const bool c_plain = EPI != PP_EPI_ACT && p.c.rows_per_batch <= 0, e_plain = EPI != PP_EPI_ACT && p.e.rows_per_batch <= 0;
     const bool need_e = EPI == PP_EPI_ACT;          // (side rows compute their own offsets in side_load)
     const smx_f2 al2 = SMX_PK(p.alpha);
-    constexpr int QB = EPI == PP_EPI_F32 ? 2 : 1;         // row visits per batch: what fits beside the 64 accumulator registers
+    constexpr int QB = QBX ? QBX : EPI == PP_EPI_F32 ? 2 : 1;         // row visits per batch: what fits beside the 64 accumulator registers
     // residual / pre-activation rows are requested one batch AHEAD of their use (across the two halves too), so their
     // latency sits behind the previous batch's arithmetic and the LDS round trip instead of in front of every row visit
     constexpr bool SIDE = EPI == PP_EPI_ACTGRAD || EPI == PP_EPI_LINEAR;
@@ -733,13 +733,14 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
             if (epi == PP_EPI_LINEAR) TR1_GO(false, false, PP_EPI_LINEAR);
             else if (epi == PP_EPI_ACT && flagged) TR1_GO(false, false, 4);
             else if (epi == PP_EPI_ACT) TR1_GO(false, false, PP_EPI_ACT);
+            else if (epi == PP_EPI_F32) TR1_GO(false, false, PP_EPI_F32);        // split-K slabs of the decoder-side GEMMs
             else TR1_GO(false, false, -1);
         } else if (!p.a_rc && p.b_rc) {
             if (epi == PP_EPI_LINEAR) TR1_GO(false, true, PP_EPI_LINEAR);
             else if (epi == PP_EPI_ACTGRAD && flagged && !p.bias) TR1_GO(false, true, 5);
             else if (flagged) return SMX_EINVAL;
             else if (epi == PP_EPI_ACTGRAD) TR1_GO(false, true, PP_EPI_ACTGRAD);
-            else TR1_GO(false, true, -1);
+            else TR1_GO(false, true, -1);        // (the F32 class of this layout does not fit 128 registers: generic form)
         } else if (p.a_rc && !p.b_rc) {
             TR1_GO(true, false, -1);
         } else {
