@@ -283,12 +283,14 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
 // pre-activation / accumulate target) issued first, all eight LDS reads together, then the arithmetic of the class only,
 // then the stores - with no ragged-tail path and no per-visit flag tests.  The generic form spent ~3.5 us per tile here
 // (a quarter of a K = 768 launch: the workgroups of a CU reach their epilogues together and are bound by VALU issue).
-// EPIX: class of gemm_common.h, or 4 / 5 = ACT / ACTGRAD whose side tensor is the local derivative (SMX_ACT_SAVE_GRAD)
+// EPIX: class of gemm_common.h, or 4 / 5 = ACT / ACTGRAD whose side tensor is the local derivative (SMX_ACT_SAVE_GRAD),
+// or 6 = F32 without the accumulate form
 template <int EPIX, int QBX = 0>       // QBX: row visits per batch (0: by class)
 __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
                                                      long long zc, long long zbias, long long ze, int lane) {
-    constexpr int EPI = EPIX == 4 ? PP_EPI_ACT : EPIX == 5 ? PP_EPI_ACTGRAD : EPIX;
-    constexpr bool sg = EPIX >= 4;
+    constexpr int EPI = EPIX == 4 ? PP_EPI_ACT : EPIX == 5 ? PP_EPI_ACTGRAD : EPIX == 6 ? PP_EPI_F32 : EPIX;
+    constexpr bool sg = EPIX == 4 || EPIX == 5;
+    constexpr bool F32_PLAIN = EPIX == 6;          // fp32 output that is only written (split-K slabs): no read-modify-write state
     const int i16 = lane & 15, g = lane >> 4;
     const int rr = lane >> 3, cc = lane & 7;
     const int n = nw0 + cc * 8;
@@ -303,7 +305,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
     const bool drop = EPI != PP_EPI_F32 && p.drop_p > 0.f;
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
-    const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
+    const bool has_acc = EPI == PP_EPI_F32 && !F32_PLAIN && p.atomic == 2;
     const bool has_aux = EPI == PP_EPI_ACT && p.aux_out;
     const int act = p.act & 0xff;
     // (the ACT class has no register to spare for the second addressing form: it keeps view_off)
@@ -340,7 +342,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
             long long cb[QB], eb[QB];
             bool ok[QB];
             uint4 side[QB];
-            float4 old[EPI == PP_EPI_F32 ? QB : 1][2];
+            float4 old[(EPI == PP_EPI_F32 && !F32_PLAIN) ? QB : 1][2];
             f32x4_t lo[QB], hi[QB];
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) {
@@ -352,7 +354,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                 eb[qi] = !need_e ? 0 : ze + n + (e_plain ? p.e.off + (long long)mm * p.e.ld : view_off(p.e, mm));
                 if constexpr (SIDE) {
                     side[qi] = side_nxt[qi];
-                } else if (EPI == PP_EPI_F32) {
+                } else if (EPI == PP_EPI_F32 && !F32_PLAIN) {
                     if (has_acc && ok[qi]) {
                         const float* c = reinterpret_cast<const float*>(p.C) + cb[qi];
                         old[qi][0] = *reinterpret_cast<const float4*>(c);
@@ -386,6 +388,14 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                         x[e] = r[0];
                         x[e + 1] = r[1];
                     }
+                }
+                if (EPI == PP_EPI_F32 && F32_PLAIN) {
+                    if (ok[qi]) {
+                        float* c = reinterpret_cast<float*>(p.C) + cb[qi];
+                        *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
+                        *reinterpret_cast<float4*>(c + 4) = make_float4(x[4], x[5], x[6], x[7]);
+                    }
+                    continue;
                 }
                 if (EPI == PP_EPI_F32) {
                     x[0] += old[qi][0].x; x[1] += old[qi][0].y; x[2] += old[qi][0].z; x[3] += old[qi][0].w;
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
         asm volatile("" : "+s"(ka));
         const SmxGemmParams& pe = *(const SmxGemmParams*)ka;
         if constexpr (EPI >= 0)
-            epilogue_staged_fast<EPI>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+            epilogue_staged_fast<EPI, (EPI == 6 && !A_RC && B_RC) ? 1 : 0>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
         else
             epilogue_staged(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
     }
@@ -733,18 +743,21 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
             if (epi == PP_EPI_LINEAR) TR1_GO(false, false, PP_EPI_LINEAR);
             else if (epi == PP_EPI_ACT && flagged) TR1_GO(false, false, 4);
             else if (epi == PP_EPI_ACT) TR1_GO(false, false, PP_EPI_ACT);
-            else if (epi == PP_EPI_F32) TR1_GO(false, false, PP_EPI_F32);        // split-K slabs of the decoder-side GEMMs
+            else if (epi == PP_EPI_F32 && p.atomic == 0) TR1_GO(false, false, 6);  // split-K slabs of the decoder-side GEMMs
+            else if (epi == PP_EPI_F32) TR1_GO(false, false, PP_EPI_F32);
             else TR1_GO(false, false, -1);
         } else if (!p.a_rc && p.b_rc) {
             if (epi == PP_EPI_LINEAR) TR1_GO(false, true, PP_EPI_LINEAR);
             else if (epi == PP_EPI_ACTGRAD && flagged && !p.bias) TR1_GO(false, true, 5);
             else if (flagged) return SMX_EINVAL;
             else if (epi == PP_EPI_ACTGRAD) TR1_GO(false, true, PP_EPI_ACTGRAD);
-            else TR1_GO(false, true, -1);        // (the F32 class of this layout does not fit 128 registers: generic form)
+            else if (epi == PP_EPI_F32 && p.atomic == 0) TR1_GO(false, true, 6);
+            else TR1_GO(false, true, -1);        // (the accumulate form of F32 does not fit 128 registers in this layout)
         } else if (p.a_rc && !p.b_rc) {
             TR1_GO(true, false, -1);
         } else {
-            if (epi == PP_EPI_F32) TR1_GO(true, true, PP_EPI_F32);
+            if (epi == PP_EPI_F32 && p.atomic == 0) TR1_GO(true, true, 6);
+            else if (epi == PP_EPI_F32) TR1_GO(true, true, PP_EPI_F32);
             else TR1_GO(true, true, -1);
         }
 #undef TR1_GO
