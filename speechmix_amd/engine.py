@@ -121,6 +121,8 @@ class Engine:
         ksteps = (Kred + 63) // 64
         # 4 workgroups/CU x 256 CUs are resident at once: aim for ~1 full wave of workgroups, keep every split
         # non-empty and at least 8 K-steps long (slab traffic grows with the split count)
+        if ksteps <= 16 and tiles >= 96:
+            return 1      # short reductions over >= 96 tiles (decoder weight gradients): the slab pass costs more than it returns
         want = int(max(1, min(1024 // max(tiles, 1), ksteps // 8, 32)))       # floor: one resident wave, no tail round
         per = (ksteps + want - 1) // want
         return (ksteps + per - 1) // per
@@ -133,10 +135,11 @@ class Engine:
             return 1
         tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
         ksteps = (Kred + 63) // 64
-        if tiles > 256 or ksteps < 6:
+        # measured under rocprofv3 (tools/gpu_small_gemm.py trace): a 128x128 launch costs ~8 us + 0.8 us per K step, the slab
+        # pass ~7 us more - up to 16 K steps (K <= 1024) one launch wins, beyond that ~8 K steps per split
+        if tiles > 256 or ksteps <= 16:
             return 1
-        # up to 4 resident workgroups per CU; keep >= 3-4 K steps per split (slab traffic grows with the split count)
-        want = int(min(1024 // tiles, ksteps // 3 if ksteps <= 16 else ksteps // 4, 24))
+        want = int(min(1024 // tiles, ksteps // 8, 24))
         if want < 2:
             return 1
         per = (ksteps + want - 1) // want
