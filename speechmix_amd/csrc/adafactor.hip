@@ -172,7 +172,20 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
     const float* cacc = o.cacc + T.col_off + (long long)sg.b * T.C;
     const float ic = 1.0f / (float)T.C, ir = 1.0f / (float)T.R;
     float s = 0.f;
-    for (int r = threadIdx.x; r < T.R; r += 256) {
+    // (the embedding's 50 k rows are one segment, 196 trips per thread: eight trips' loads in flight instead of one)
+    int r = threadIdx.x;
+    for (; r + 7 * 256 < T.R; r += 8 * 256) {
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = row[r + i * 256]; b[i] = racc[r + i * 256]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = b2 * a[i] + (1.f - b2) * (b[i] * ic);
+            row[r + i * 256] = v;
+            s += v;
+        }
+    }
+    for (; r < T.R; r += 256) {
         const float v = b2 * row[r] + (1.f - b2) * (racc[r] * ic);
         row[r] = v;
         s += v;
