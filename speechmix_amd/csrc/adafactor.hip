@@ -117,34 +117,52 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) cs[j][e] = 0.f;
-    for (int r = tl.r0 + w; r < tl.r0 + tl.nr; r += 4) {
-        const float* gr = g + (long long)r * T.C + tl.c0;
-        float rs = 0.f;
+    // two rows per trip with all their loads issued first: a wave walks 16+ rows of a tile, and one row's 16-B loads are
+    // too few bytes in flight to stream at HBM speed
+    for (int r = tl.r0 + w; r < tl.r0 + tl.nr; r += 8) {
+        const bool two = r + 4 < tl.r0 + tl.nr;
+        float x[2][NJ][4];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int c = 4 * (lane + 64 * j);
-            if (c < tl.nc) {
-                float x[4];
-                if (v4) {
-                    const float4 q = *reinterpret_cast<const float4*>(gr + c);
-                    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-                } else {
+        for (int k = 0; k < 2; ++k) {
+            const float* gr = g + (long long)(r + 4 * k) * T.C + tl.c0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = c + e < tl.nc ? gr[c + e] : 0.f;
-                }
+            for (int j = 0; j < NJ; ++j) {
+                const int c = 4 * (lane + 64 * j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gi = x[e] * gs;
-                    const float u = (v4 || c + e < tl.nc) ? gi * gi + o.eps1 : 0.f;
-                    rs += u;
-                    cs[j][e] += u;
+                for (int e = 0; e < 4; ++e) x[k][j][e] = 0.f;
+                if (c < tl.nc && (k == 0 || two)) {
+                    if (v4) {
+                        const float4 q = *reinterpret_cast<const float4*>(gr + c);
+                        x[k][j][0] = q.x; x[k][j][1] = q.y; x[k][j][2] = q.z; x[k][j][3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[k][j][e] = c + e < tl.nc ? gr[c + e] : 0.f;
+                    }
                 }
             }
         }
-        rs = wave_sum(rs);
-        if (lane == 0) {
-            if (tl.full_rows) racc[r] = rs;
-            else atomicAdd(racc + r, rs);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !two) break;
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = 4 * (lane + 64 * j);
+                if (c < tl.nc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gi = x[k][j][e] * gs;
+                        const float u = (v4 || c + e < tl.nc) ? gi * gi + o.eps1 : 0.f;
+                        rs += u;
+                        cs[j][e] += u;
+                    }
+                }
+            }
+            rs = wave_sum(rs);
+            if (lane == 0) {
+                if (tl.full_rows) racc[r + 4 * k] = rs;
+                else atomicAdd(racc + r + 4 * k, rs);
+            }
         }
     }
 #pragma unroll
