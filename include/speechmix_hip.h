@@ -23,6 +23,10 @@ extern "C" {
 
 enum { SMX_F32 = 0, SMX_BF16 = 1 };
 enum { SMX_ACT_NONE = 0, SMX_ACT_GELU = 1, SMX_ACT_RELU = 2 };
+/* OR-ed into SmxGemmParams.act (bf16 GEMMs, forward with aux_out / data gradient with aux_in, and the split-K epilogue):
+ * the side tensor holds the epilogue's LOCAL DERIVATIVE act'(pre) * dropout multiplier instead of the pre-activation; the
+ * backward launch multiplies it in (no activation gradient, no dropout hash there).  Launches outside those forms: EINVAL. */
+#define SMX_ACT_SAVE_GRAD 0x100
 
 /* logical row r of an operand -> element offset: off + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * ld
  * (rows_per_batch <= 0: off + r * ld).  Lets a Conv1d be a GEMM over overlapping windows of a [B,T,C] activation. */
