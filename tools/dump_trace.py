@@ -1,3 +1,4 @@
+"""Raw kernel durations around the first marker of a rocprofv3 --kernel-trace CSV (debug aid for tools/trace_cfgs.py)."""
 import csv, sys
 rows=[]
 for r in csv.DictReader(open(sys.argv[1])):
