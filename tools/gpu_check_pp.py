@@ -32,7 +32,7 @@ def cmp(name, got, ref, tol=2e-2):
 
 
 TRS = tuple(int(x) for x in os.environ.get("SMX_CHECK_TRS", "8").split(","))
-KC_ONLY = (12,)          # kernels that only take K-contiguous operands
+KC_ONLY = tuple(int(x) for x in os.environ.get("SMX_CHECK_KC_ONLY", "").split(",") if x)   # kernels that only take K-contiguous operands
 
 
 def main():

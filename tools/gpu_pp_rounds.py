@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 labs = [int(x) for x in sys.argv[2:]] or [0]
 N = 1024
-for tr in [8 + (l << 8) for l in labs] + [1]:
+for tr in [8 + (l << 8) for l in labs] + [int(x) for x in os.environ.get("SMX_ROUNDS_EXTRA", "").split(",") if x] + [1]:
     ts = []
     for r in (1, 2, 4, 8):
         M = 16128 * r
