@@ -1,6 +1,7 @@
 // Small HBM-bound kernels around the GEMMs: dtype casts, conv-weight re-layouts, token embedding
 // gather / scatter, bias-gradient column sums, fused cross-entropy (+argmax, +dlogits), SpecAugment row
 // masking, element-wise adds.  All fp32 statistics; 16-B accesses where layouts allow.
+#include <cstdlib>
 #include "smx_common.h"
 
 // ---------------------------------------------------------------- cast fp32 -> T
@@ -434,14 +435,106 @@ __global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
         }
     }
 }
+// Same results for the plain loss (labels, no teacher logits) in two passes over the row instead of three, 16-B accesses:
+// pass 1 keeps a running (max, sum of exp, first arg max) per thread and merges them across the block, pass 2 writes the
+// gradient.  The 200-KB fp32 row of the BART vocabulary stays in L2 between the passes.
+struct CeRun {
+    float m, s;
+    int i;
+};
+__device__ __forceinline__ void ce_merge(CeRun& a, float om, float os, int oi) {
+    if (om == -INFINITY) return;
+    if (a.m == -INFINITY) { a.m = om; a.s = os; a.i = oi; return; }
+    const float M = fmaxf(a.m, om);
+    a.s = a.s * __expf(a.m - M) + os * __expf(om - M);
+    if (om > a.m || (om == a.m && oi < a.i)) a.i = oi;
+    a.m = M;
+}
+__device__ __forceinline__ void ce_push(CeRun& a, float v, int idx) {
+    if (v > a.m) {                      // strictly greater: the first index of the maximum is kept
+        a.s = a.s * __expf(a.m - v) + 1.f;        // (exp(-inf) = 0 on the first element)
+        a.m = v;
+        a.i = idx;
+    } else {
+        a.s += __expf(v - a.m);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fast_kernel(SmxCEParams p) {
+    __shared__ float sh[16];
+    __shared__ float shm[4], shs[4];
+    __shared__ int shi[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* z = p.logits + (long long)row * p.ldl;
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const int nv4 = p.V >> 2;
+    float nvalid = 0.f;
+    for (int i = tid; i < p.M; i += 256) nvalid += p.labels[i] != -100 ? 1.f : 0.f;
+    nvalid = block_sum(nvalid, sh);
+    CeRun a = {-INFINITY, 0.f, 0x7fffffff};
+    for (int j4 = tid; j4 < nv4; j4 += 256) {
+        const float4 v = z4[j4];
+        const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        if (m4 > a.m) {
+            const int k = v.x == m4 ? 0 : v.y == m4 ? 1 : v.z == m4 ? 2 : 3;
+            a.s *= __expf(a.m - m4);
+            a.m = m4;
+            a.i = j4 * 4 + k;
+        }
+        a.s += (__expf(v.x - a.m) + __expf(v.y - a.m)) + (__expf(v.z - a.m) + __expf(v.w - a.m));
+    }
+    if (tid == 0)
+        for (int j = nv4 * 4; j < p.V; ++j) ce_push(a, z[j], j);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(a.m, o, 64), os = __shfl_xor(a.s, o, 64);
+        const int oi = __shfl_xor(a.i, o, 64);
+        ce_merge(a, om, os, oi);
+    }
+    if (lane == 0) { shm[w] = a.m; shs[w] = a.s; shi[w] = a.i; }
+    __syncthreads();
+    a.m = shm[0]; a.s = shs[0]; a.i = shi[0];
+    for (int k = 1; k < 4; ++k) ce_merge(a, shm[k], shs[k], shi[k]);
+    if (p.argmax && tid == 0) p.argmax[row] = a.i;
+    const float lse = a.m + __logf(a.s);
+    if (p.lse && tid == 0) p.lse[row] = lse;
+    const long long lab = p.labels[row];
+    const bool valid = lab != -100;
+    if (valid && tid == 0) atomicAdd(p.loss, (lse - z[lab]) / nvalid);
+    if (!p.dlogits) return;
+    T* d = reinterpret_cast<T*>(p.dlogits) + (long long)row * p.ldd;
+    const float coef = valid ? p.gscale / nvalid : 0.f;
+    const int lab4 = valid ? (int)(lab >> 2) : -1, labk = (int)(lab & 3);
+    for (int j4 = tid; j4 < nv4; j4 += 256) {
+        const float4 v = z4[j4];
+        float g[4] = {__expf(v.x - lse) * coef, __expf(v.y - lse) * coef, __expf(v.z - lse) * coef, __expf(v.w - lse) * coef};
+        if (j4 == lab4) g[labk] -= coef;
+        if (sizeof(T) == 2) *reinterpret_cast<uint2*>(d + j4 * 4) = make_uint2(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]));
+        else *reinterpret_cast<float4*>(d + j4 * 4) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    for (int j = nv4 * 4 + tid; j < p.ldd; j += 256) {          // ragged end of the vocabulary, then the zeroed pad columns
+        float g = 0.f;
+        if (j < p.V) g = (__expf(z[j] - lse) - ((valid && j == lab) ? 1.f : 0.f)) * coef;
+        Cvt<T>::st(d + j, g);
+    }
+}
 extern "C" int smx_cross_entropy(const SmxCEParams* pp, int dtype, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxCEParams p = *pp;
     if (p.M <= 0 || p.V <= 0 || p.ldl < p.V) return SMX_EINVAL;
     if (p.dlogits && p.ldd < p.V) return SMX_EINVAL;
+    if (dtype != SMX_BF16 && dtype != SMX_F32) return SMX_EINVAL;
+    // plain loss on 16-B aligned rows: the two-pass kernel (SMX_CE_FAST=0: off)
+    static const bool fast_ok = !(getenv("SMX_CE_FAST") && getenv("SMX_CE_FAST")[0] == '0');
+    const bool fast = fast_ok && p.labels && p.loss && !p.logits_t && !(p.ldl & 3) && !((size_t)p.logits & 15) &&
+                      (!p.dlogits || (!(p.ldd & 3) && !((size_t)p.dlogits & 15)));
+    if (fast) {
+        if (dtype == SMX_BF16) hipLaunchKernelGGL(ce_fast_kernel<bf16_t>, dim3(p.M), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(ce_fast_kernel<float>, dim3(p.M), dim3(256), 0, stream, p);
+        SMX_CHECK_LAUNCH();
+    }
     if (dtype == SMX_BF16) hipLaunchKernelGGL(ce_kernel<bf16_t>, dim3(p.M), dim3(256), 0, stream, p);
-    else if (dtype == SMX_F32) hipLaunchKernelGGL(ce_kernel<float>, dim3(p.M), dim3(256), 0, stream, p);
-    else return SMX_EINVAL;
+    else hipLaunchKernelGGL(ce_kernel<float>, dim3(p.M), dim3(256), 0, stream, p);
     SMX_CHECK_LAUNCH();
 }
 

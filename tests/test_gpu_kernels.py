@@ -246,3 +246,29 @@ def test_saved_activation_derivative_matches_the_recomputed_one():
     assert (S0.float() - S1.float()).abs().max().item() <= 2e-2
     with pytest.raises(RuntimeError):
         ops.gemm(A, W, Y0, M, N, K, ops.BF16, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out=S0, resid=Y1, tr_mode=1)
+
+
+@pytest.mark.parametrize("V", [50265, 130, 64])
+def test_cross_entropy_two_pass_kernel_matches_torch(V):
+    """loss (mean over valid tokens, ignore_index -100), first arg max and d loss / d logits of the vectorised two-pass kernel."""
+    import torch
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(V)
+    M, Vp = 96, (V + 7) // 8 * 8
+    logits = torch.zeros(M, Vp, device=dev)
+    logits[:, :V] = torch.randn(M, V, device=dev) * 3
+    logits[5, 7] = logits[5, 3] = 50.0                      # a tie: the FIRST index wins (torch.argmax semantics on CPU)
+    labels = torch.randint(0, V, (M,), device=dev)
+    labels[::7] = -100
+    for dt, tdt, tol in ((ops.F32, torch.float32, 1e-6), (ops.BF16, torch.bfloat16, 1e-2)):
+        loss = torch.zeros(1, device=dev); am = torch.empty(M, dtype=torch.int64, device=dev)
+        dl = torch.full((M, Vp), 7.0, dtype=tdt, device=dev)
+        ops.cross_entropy(logits, labels, loss, am, dl, M, V, Vp, Vp, dt, gscale=2.0)
+        ref_in = logits[:, :V].clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(ref_in, labels, ignore_index=-100)
+        (2.0 * ref).backward()
+        assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+        assert am[5].item() == 3 and torch.equal(am, logits[:, :V].cpu().argmax(-1).to(dev))
+        assert (dl[:, :V].float() - ref_in.grad).abs().max().item() <= tol * ref_in.grad.abs().max().item() + 1e-9
+        assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
