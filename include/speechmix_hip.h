@@ -88,6 +88,8 @@ int smx_conv0_bwd(const SmxConv0Params* p, int dtype, hipStream_t stream);
 
 /* positional conv helpers (group-major pack, weight_norm forward/backward). TF:...wav2vec2.py:326-379 */
 int smx_group_pack(const void* x, void* xg, int B, int T, int C, int G, int K, int pad_front, int dtype, hipStream_t stream);
+/* norm and scratch_s: K * (1 + smx_wn_partial_blocks(C, Cg)) floats each (results in the first K; K <= 256) */
+int smx_wn_partial_blocks(int C, int Cg);
 int smx_wn_fwd(const float* v, const float* g, void* wp, void* wf, float* norm, int C, int Cg, int K, int dtype, hipStream_t stream);
 int smx_wn_bwd(const float* dwp, const float* v, const float* g, const float* norm, float* scratch_s, float* dg, float* dv,
                int C, int Cg, int K, hipStream_t stream);

@@ -39,16 +39,48 @@ extern "C" int smx_group_pack(const void* x, void* xg, int B, int T, int C, int 
 }
 
 // norm[k] = || v[:, :, k] ||_2   (v: [C, Cg, K]); one block per tap
-__global__ __launch_bounds__(256) void wn_norm_kernel(const float* __restrict__ v, float* __restrict__ norm, int C, int Cg, int K) {
+// Norms over (co, ci) for every tap k of v[co][ci][k] (k fastest).  A block owns WN_ROWS (co, ci) rows, its threads walk
+// along k (coalesced 512-B reads; one block per k read every 128th float of the whole tensor instead) and leave one partial
+// row [K]; a second tiny launch adds the partial rows in order (deterministic) and takes the root.
+#define WN_ROWS 64
+extern "C" int smx_wn_partial_blocks(int C, int Cg) { return (C * Cg + WN_ROWS - 1) / WN_ROWS; }
+// s_part[blk][k] = sum over the block's rows of a[row][k] * b[row][k]   (b == a: squares); K <= 256, 256 threads
+__global__ __launch_bounds__(256) void wn_partial_kernel(const float* __restrict__ v, const float* __restrict__ dwp, float* __restrict__ part,
+                                                         int rows, int Cg, int K) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const int lanes_k = K <= 128 ? 128 : 256;               // threads along k; the rest of the block takes other rows
+    const int k = tid % lanes_k, h = tid / lanes_k, nh = 256 / lanes_k;
+    const int r0 = blockIdx.x * WN_ROWS, r1 = min(rows, r0 + WN_ROWS);
+    float s = 0.f;
+    if (k < K) {
+#pragma unroll 8
+        for (int r = r0 + h; r < r1; r += nh) {             // (independent trips: several loads in flight)
+            const float a = v[(long long)r * K + k];
+            float b = a;
+            if (dwp) {                                       // backward: dW in the forward-pack layout [co][k*Cg+ci]
+                const int ci = r % Cg, co = r / Cg;
+                b = dwp[((long long)co * K + k) * Cg + ci];
+            }
+            s += a * b;
+        }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (h == 0 && k < K) {
+        float a = red[k];
+        for (int j = 1; j < nh; ++j) a += red[j * lanes_k + k];
+        part[(long long)blockIdx.x * K + k] = a;
+    }
+}
+// out[k] = (root of) the sum of the nb partial rows, one block per k, partial rows added in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void wn_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, int K, int root) {
     __shared__ float sh[16];
     const int k = blockIdx.x;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < C * Cg; i += 256) {
-        const float a = v[(long long)i * K + k];
-        s += a * a;
-    }
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) norm[k] = sqrtf(s);
+    float a = 0.f;
+    for (int j = threadIdx.x; j < nb; j += 256) a += part[(long long)j * K + k];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) out[k] = root ? sqrtf(a) : a;
 }
 template <typename T>
 __global__ void wn_pack_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ norm,
@@ -65,7 +97,10 @@ __global__ void wn_pack_kernel(const float* __restrict__ v, const float* __restr
 extern "C" int smx_wn_fwd(const float* v, const float* g, void* wp, void* wf, float* norm, int C, int Cg, int K, int dtype,
                           hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
-    hipLaunchKernelGGL(wn_norm_kernel, dim3(K), dim3(256), 0, stream, v, norm, C, Cg, K);
+    if (K > 256 || K <= 0) return SMX_EINVAL;
+    const int nb = smx_wn_partial_blocks(C, Cg);             // norm: [K] norms followed by nb x K floats of scratch
+    hipLaunchKernelGGL(wn_partial_kernel, dim3(nb), dim3(256), 0, stream, v, (const float*)nullptr, norm + K, C * Cg, Cg, K);
+    hipLaunchKernelGGL(wn_finish_kernel, dim3(K), dim3(256), 0, stream, norm + K, norm, nb, K, 1);
     const long long n = (long long)C * Cg * K;
     int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     if (dtype == SMX_BF16) hipLaunchKernelGGL(wn_pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, v, g, norm, (bf16_t*)wp, (bf16_t*)wf, C, Cg, K);
@@ -76,18 +111,6 @@ extern "C" int smx_wn_fwd(const float* v, const float* g, void* wp, void* wf, fl
 
 // dwp: fp32 [C][k*Cg+ci] (the forward-pack layout).  s[k] = sum dW*v;  dg[k] += s/norm;
 // dv += g/norm * dW - g*s/norm^3 * v
-__global__ __launch_bounds__(256) void wn_bwd_dot_kernel(const float* __restrict__ dwp, const float* __restrict__ v,
-                                                         float* __restrict__ s, int C, int Cg, int K) {
-    __shared__ float sh[16];
-    const int k = blockIdx.x;
-    float a = 0.f;
-    for (int i = threadIdx.x; i < C * Cg; i += 256) {
-        const int ci = i % Cg, co = i / Cg;
-        a += dwp[((long long)co * K + k) * Cg + ci] * v[(long long)i * K + k];
-    }
-    a = block_sum(a, sh);
-    if (threadIdx.x == 0) s[k] = a;
-}
 __global__ void wn_bwd_apply_kernel(const float* __restrict__ dwp, const float* __restrict__ v, const float* __restrict__ g,
                                     const float* __restrict__ norm, const float* __restrict__ s, float* __restrict__ dg,
                                     float* __restrict__ dv, int C, int Cg, int K) {
@@ -103,7 +126,10 @@ __global__ void wn_bwd_apply_kernel(const float* __restrict__ dwp, const float* 
 extern "C" int smx_wn_bwd(const float* dwp, const float* v, const float* g, const float* norm, float* scratch_s, float* dg,
                           float* dv, int C, int Cg, int K, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
-    hipLaunchKernelGGL(wn_bwd_dot_kernel, dim3(K), dim3(256), 0, stream, dwp, v, scratch_s, C, Cg, K);
+    if (K > 256 || K <= 0) return SMX_EINVAL;
+    const int nb = smx_wn_partial_blocks(C, Cg);             // scratch_s: [K] dots followed by nb x K floats
+    hipLaunchKernelGGL(wn_partial_kernel, dim3(nb), dim3(256), 0, stream, v, dwp, scratch_s + K, C * Cg, Cg, K);
+    hipLaunchKernelGGL(wn_finish_kernel, dim3(K), dim3(256), 0, stream, scratch_s + K, scratch_s, nb, K, 0);
     const long long n = (long long)C * Cg * K;
     int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(wn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, dwp, v, g, norm, scratch_s, dg, dv, C, Cg, K);

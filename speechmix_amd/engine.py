@@ -612,7 +612,7 @@ class Engine:
         Cg, P, Tp = d // G, ec.num_conv_pos_embeddings // 2, T + ec.num_conv_pos_embeddings - 1
         pre_n = f"{ep}encoder.pos_conv_embed.conv."
         wp = self.new(G * Cg * K * Cg)
-        norm = self.new(K, dt=torch.float32)
+        norm = self.new(ops.wn_scratch_floats(d, Cg, K), dt=torch.float32)        # [K] norms, then reduction scratch
         ops.wn_fwd(self.P(pre_n + "parametrizations.weight.original1"), self.P(pre_n + "parametrizations.weight.original0"),
                    wp, None, norm, d, Cg, K, self.dt)
         xg = self.new(G * B * Tp * Cg)
@@ -643,7 +643,7 @@ class Engine:
                      bv=view(Cg, T, Tp * Cg), cv=view(K * Cg), out_f32=True, atomic=0, split_k=split, split_stride=n,
                      nbatch=G, batch_a=Cg, batch_b=B * Tp * Cg, batch_c=Cg * K * Cg)
             ops.reduce_slabs(slabs, split, n, n, dwp, accumulate=False)
-            scratch = self.new(K, dt=torch.float32)
+            scratch = self.new(ops.wn_scratch_floats(d, Cg, K), dt=torch.float32)
             ops.wn_bwd(dwp, self.P(v_n), self.P(g_n), sv["norm"], scratch, self.G(g_n), self.G(v_n), d, Cg, K)
         dyg = self.new(G * B * Tp * Cg)
         ops.group_pack(dpre, dyg, B, T, d, G, K, K - 1 - P, self.dt)

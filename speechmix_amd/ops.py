@@ -458,6 +458,11 @@ def group_pack(x, xg, B, T, Cc, G, K, pad_front, dtype):
                                    _stream()), "smx_group_pack")
 
 
+def wn_scratch_floats(Cc, Cg, K):
+    """Size of the `norm` / `scratch` buffers of wn_fwd / wn_bwd: K results followed by the partial rows of their reductions."""
+    return K * (1 + L.lib().smx_wn_partial_blocks(Cc, Cg))
+
+
 def wn_fwd(v, g, wp, wf, norm, Cc, Cg, K, dtype):
     L.check(L.lib().smx_wn_fwd(C.c_void_p(_ptr(v)), C.c_void_p(_ptr(g)), C.c_void_p(_ptr(wp)), C.c_void_p(_ptr(wf)),
                                C.c_void_p(_ptr(norm)), Cc, Cg, K, dtype, _stream()), "smx_wn_fwd")
