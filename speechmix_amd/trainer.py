@@ -34,8 +34,14 @@ def trainable_ranges(store) -> List[Tuple[int, int]]:
 
 class StepRunner:
     def __init__(self, model, lr=4e-5, optimizer="adamw", betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_grad_norm=1.0, momentum=0.0, force_comm=False):
+                 max_grad_norm=1.0, momentum=0.0, force_comm=False, grad_accum=1):
+        """grad_accum: micro-batches per optimizer step (the reference trains with HF Trainer's
+        gradient_accumulation_steps, ref:train.py:159, 295: every micro-batch's loss is divided by it, gradients add up, and
+        the all-reduce / clip / optimizer update run on the last one)."""
         model._need_engine()
+        self.grad_accum = max(1, int(grad_accum))
+        self._micro = 0
+        self._dropped_all = set()
         self.model, self.store, self.engine = model, model.store, model.engine
         self.kind = optimizer
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm, self.momentum = lr, betas, eps, weight_decay, \
@@ -81,12 +87,25 @@ class StepRunner:
         labels = labels.to(st.device)
         if decoder_input_ids is None:
             decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
-        self.reducer.begin_step()
+        ga, first = self.grad_accum, self._micro == 0
+        last = self._micro == ga - 1
+        self._micro = 0 if last else self._micro + 1
+        if first:
+            self.reducer.begin_step()
         text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
         out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(),
                           training=m.training and m.encoder_model.training, text_ids=text, weighted_sum=m.weighted_sum,
                           lm_training=m._lm_training())
-        eng.backward(gscale=1.0, zero_grads=True)
+        # micro-batches before the last only add their gradient (no stage reports: nothing is reduced or updated yet)
+        cb, eng.stage_cb = eng.stage_cb, (eng.stage_cb if last else None)
+        try:
+            eng.backward(gscale=1.0 / ga, zero_grads=first)
+        finally:
+            eng.stage_cb = cb
+        # LayerDrop: a layer is without a gradient for this update only if every micro-batch dropped it
+        self._dropped_all = set(eng.last_dropped) if first else (self._dropped_all & set(eng.last_dropped))
+        if not last:
+            return out["loss"]
         self.reducer.finish()
         self.t += 1
         inv_world = 1.0 / self.world
@@ -96,8 +115,8 @@ class StepRunner:
         sh = None if st.shadow is st.master else st.shadow
         if self.af is not None:
             active = None
-            if self.world == 1 and eng.last_dropped:      # HF skips parameters without a gradient (a dropped layer's);
-                dropped = set(eng.last_dropped)           # across ranks the all-reduce gives every tensor a gradient
+            if self.world == 1 and self._dropped_all:     # HF skips parameters without a gradient (a dropped layer's);
+                dropped = self._dropped_all               # across ranks the all-reduce gives every tensor a gradient
                 active = [l not in dropped for l in self._af_layer]
             self.af.step(st.master, st.grad, sh, self.gnorm_sq if clip > 0 else None, self.lr, active=active,
                          grad_scale=inv_world, max_grad_norm=clip)

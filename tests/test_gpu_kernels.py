@@ -272,3 +272,30 @@ def test_cross_entropy_two_pass_kernel_matches_torch(V):
         assert am[5].item() == 3 and torch.equal(am, logits[:, :V].cpu().argmax(-1).to(dev))
         assert (dl[:, :V].float() - ref_in.grad).abs().max().item() <= tol * ref_in.grad.abs().max().item() + 1e-9
         assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+
+
+def test_gradient_accumulation_equals_one_step_on_the_concatenated_batch():
+    """StepRunner(grad_accum=2) over two micro-batches == one step over their concatenation (fp32, eval mode, SGD): the
+    loss of every micro-batch is divided by the count, gradients add up, the update runs on the last one."""
+    import torch
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.trainer import StepRunner
+    from tests.golden_util import load_case
+    sd, inp, gold, m = load_case("eed_w2v2_bart")
+    wave, labels = inp["input_values"], inp["labels"].clone()
+    labels[labels == -100] = 5                      # same number of valid tokens in both halves: mean of means == global mean
+    def fresh():
+        model = SpeechMixEED(m["enc_cfg"], m["lm_cfg"], down_scale=2, compute_dtype="fp32").eval()
+        model.load_state_dict(sd, strict=False)
+        return model
+    a = fresh()
+    ra = StepRunner(a, lr=1e-2, optimizer="sgd", max_grad_norm=0.0)
+    ra.step(wave, labels)
+    b = fresh()
+    rb = StepRunner(b, lr=1e-2, optimizer="sgd", max_grad_norm=0.0, grad_accum=2)
+    before = b.store.master.clone()
+    rb.step(wave[:1], labels[:1])
+    assert torch.equal(b.store.master, before)      # nothing is updated on the first micro-batch
+    rb.step(wave[1:], labels[1:])
+    assert not torch.equal(b.store.master, before)
+    assert torch.allclose(a.store.master, b.store.master, atol=2e-6, rtol=1e-4)
