@@ -79,7 +79,7 @@ def main():
     if "ksweep" in sys.argv:
         ksweep()
         return 0
-    shapes = [(1024, 768, 768), (1024, 3072, 768), (1024, 768, 3072), (1024, 2304, 768), (7968, 768, 768), (7968, 768, 3072),
+    shapes = [] if "wg16k" in sys.argv else [(1024, 768, 768), (1024, 3072, 768), (1024, 768, 3072), (1024, 2304, 768), (7968, 768, 768), (7968, 768, 3072),
               (7968, 3072, 768), (7968, 2304, 768), (7968, 1536, 768), (7968, 768, 1536), (15968, 768, 768)]
     for (M, N, K) in shapes:
         A = torch.randn(M, K, device=dev).bfloat16()
@@ -107,8 +107,11 @@ def main():
                     t = timed(f"{name} {M}x{N}x{K} {mode}/s{sp}", lambda: run(A, Bop, Y1, M, N, K, mode, sp, slabs, **kw))
                     res.append(f"{mode}/s{sp}: {t:.1f}")
             print(f"TIME {name} M={M} N={N} K={K}: " + "  ".join(res), flush=True)
-    # weight gradients of the decoder (reduction over 1024 rows)
-    for (No, Ko, Mred) in [(768, 768, 1024), (768, 3072, 1024), (3072, 768, 1024), (2304, 768, 1024), (768, 768, 7968)]:
+    # weight gradients of the decoder (reduction over 1024 rows) and the encoder's square projections
+    wg_shapes = [(768, 768, 1024), (768, 3072, 1024), (3072, 768, 1024), (2304, 768, 1024), (768, 768, 7968)]
+    if "wg16k" in sys.argv:
+        wg_shapes = [(768, 768, 15968), (768, 768, 7968), (1536, 768, 7968)]
+    for (No, Ko, Mred) in wg_shapes:
         Yb = torch.randn(Mred, No, device=dev).bfloat16(); Xb = torch.randn(Mred, Ko, device=dev).bfloat16()
         n = No * Ko
         out0 = torch.zeros(No, Ko, device=dev); out1 = torch.zeros_like(out0)
@@ -127,7 +130,7 @@ def main():
         wg(1, s0, out0)
         res = [f"128/s{s0}: {timed(f'wgrad {No}x{Ko}x{Mred} 128/s{s0}', lambda: wg(1, s0, out0)):.1f}"]
         for mode in MODES:
-            for want in (1, 2, 4, 8):
+            for want in ((7, 14, 21, 28, 32) if "wg16k" in sys.argv else (1, 2, 4, 8)):
                 sp = valid_split(Mred, want)
                 if sp != want:
                     continue
