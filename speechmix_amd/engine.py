@@ -82,6 +82,9 @@ class Engine:
         return f
 
     def _stage(self, name):
+        if getattr(self, "_side_active", False):          # join the LM stage's weight-gradient stream
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_active = False
         if self.folds is not None:
             self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
         if self.stage_cb is not None:
@@ -174,7 +177,7 @@ class Engine:
         slabs, so the trial runs are side-effect free); the slab sum then lands in `out`."""
         n = No * Ko
         cands = [(1, self._split(No, Ko, Kred))]
-        if self.dt == BF16 and ops.pp_allowed() and cv is None:
+        if self.dt == BF16 and ops.pp_allowed() and cv is None and not getattr(self, "_side_active", False):
             sp = ops.pp_split(No, Ko, Kred)
             if ((No + 255) // 256) * ((Ko + 255) // 256) * sp >= 96 and sp > 1:
                 cands.append((8, sp))
@@ -221,15 +224,34 @@ class Engine:
                 self._wgrad_pick[key] = pick
         run(*cands[pick])
 
-    def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, **kw):
+    def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, side_ok=True, **kw):
         """gw[N,K] += dy[M,N]^T @ x[M,K];  gb[N] += colsum(dy).  The reduction over M is split across workgroups
         when the output has too few tiles to fill the chip: each split stores its fp32 partial slab and one
         streaming pass sums the slabs into the gradient (no atomics: they serialise in L2)."""
         av = dyv if dyv is not None else view(N)
         bv = xv if xv is not None else view(K)
-        self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
-        if gb is not None:
-            ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
+        side = self._side if (side_ok and getattr(self, "_side_active", False)) else None
+        if side is None:
+            self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
+            if gb is not None:
+                ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
+            return
+        # LM stage (SMX_LM_WGRAD_STREAM=0: off): a weight gradient needs nothing that is still being computed, so it runs on a
+        # second stream beside the small-grid kernels of the LM's backward (decoder: 48 workgroups per launch, text encoder:
+        # 1.5 per CU) and is joined at the end of the stage.  What keeps that safe: dy and x are never written again (every
+        # backward output is a fresh tensor; saved activations are read-only) and record_stream keeps the allocator from
+        # recycling them early; the slab workspace is used on that stream only until the join; destinations that main-stream
+        # kernels also add to (the tied embedding: side_ok=False) stay on the main stream; bias-gradient partial rows are
+        # folded after the join.  The 128x128 kernel is used there (a one-workgroup-per-CU kernel would stall the main stream).
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
+            if gb is not None:
+                ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
+        dy.record_stream(side)
+        x.record_stream(side)
 
     def ln_fwd(self, x, wname, bname, M, D, eps, rms=False, act=ACT_NONE, pos=None, pos_period=0, pos_offset=0,
                want_sum=False, drop=None):
@@ -1103,7 +1125,7 @@ class Engine:
         emb_name, escale = sv["emb_name"], sv["escale"]
         lm_trainable = self.tr(head)
         if lm_trainable:
-            self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a)
+            self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a, side_ok=False)   # (tied embedding)
         dy = self.new(Md, d)
         self.dgrad(dlogits, self.W(head), dy, Md, V, d, av=view(Vp), alpha=a)
         if t5:
@@ -1240,6 +1262,10 @@ class Engine:
         extra = sv.get("extra_denc")
         if extra is not None and gscale != 1.0:
             extra = extra * gscale
+        if os.environ.get("SMX_LM_WGRAD_STREAM") != "0" and self.st.device.type == "cuda":
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            self._side_active = True
         de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
         P = sv.get("P", 0)
         if P:

@@ -299,3 +299,25 @@ def test_gradient_accumulation_equals_one_step_on_the_concatenated_batch():
     rb.step(wave[1:], labels[1:])
     assert not torch.equal(b.store.master, before)
     assert torch.allclose(a.store.master, b.store.master, atol=2e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case,dtype", [("eed_w2v2_bart", "fp32"), ("eed_w2v2_bart", "bf16")])
+def test_lm_weight_gradients_on_the_second_stream_equal_the_single_stream_result(case, dtype, monkeypatch):
+    """The LM stage runs its weight-gradient GEMMs on a second stream (engine.Engine.wgrad); same gradients as with
+    everything on one stream, repeated to give a race a chance to show."""
+    import torch
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.trainer import StepRunner
+    from tests.golden_util import load_case
+    sd, inp, gold, m = load_case(case)
+    model = SpeechMixEED(m["enc_cfg"], m["lm_cfg"], down_scale=2, compute_dtype=dtype).eval()
+    model.load_state_dict(sd, strict=False)
+    runner = StepRunner(model, lr=0.0, optimizer="sgd", max_grad_norm=0.0)
+    monkeypatch.setenv("SMX_LM_WGRAD_STREAM", "0")
+    runner.step(inp["input_values"], inp["labels"])
+    ref = model.store.grad.clone()
+    monkeypatch.setenv("SMX_LM_WGRAD_STREAM", "1")
+    for _ in range(5):
+        runner.step(inp["input_values"], inp["labels"])
+        assert model.engine._side is not None
+        assert torch.allclose(model.store.grad, ref, atol=1e-6 if dtype == "fp32" else 1e-3, rtol=1e-5 if dtype == "fp32" else 1e-2)
