@@ -89,6 +89,21 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"1 clip x 10 s, fwd+bwd fp32 (no optimizer), median of {len(times)} after a 1 s warm-up clip"}
 
 
+def spawn_ranks(n, argv):
+    """Run this script as n torchrun workers on 127.0.0.1 (free port), children of this process; -> exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,10 +116,23 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="dropout / LayerDrop / SpecAugment off")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as CHILD processes (torch.distributed.run,
+        # one process per GPU) before anything in this process touches the GPU, pass rank 0's JSON line through and exit
+        # with the children's code.  Never a re-exec: this process stays the parent.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if os.environ.get("SMX_BENCH_SPAWN_ONLY") == "1":        # launch-path check without a GPU (tests/test_host_logic_r2.py)
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        print(json.dumps({"spawn_check": True, "rank": rank, "world": world, "gpus": args.gpus, "rank_sum": t.item()}), flush=True)
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:

@@ -74,6 +74,11 @@ typedef struct SmxAttnParams {
 } SmxAttnParams;
 int smx_attention_fwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
 int smx_attention_bwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
+/* T5 relative-position bias gradient: smx_attention_bwd with p->dbias set accumulates dbias[H,Tq,Tk] += sum_b dS; this
+ * scatter-adds it into the [buckets, H] embedding table through the int32 bucket map [Tq*Tk]
+ * (TF:models/t5/modeling_t5.py:216-279, the gather `relative_attention_bias(bucket)` run backwards). */
+int smx_attn_bias_scatter(const float* dbias, const int* bucket, float* dtable, int H, int Tq, int Tk, int nbuckets,
+                          hipStream_t stream);
 
 /* feature-extractor layer 0: Conv1d(1->C,k,stride) on the waveform, fused with GroupNorm+GELU ("group") or plain
  * ("layer" extractor).  TF:models/wav2vec2/modeling_wav2vec2.py:301-323 / 275-299. */

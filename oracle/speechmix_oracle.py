@@ -222,8 +222,22 @@ def _bart_attn(sd, p, x, kv, nh, causal=False):
     return linear(mha(q, k, v, nh, (D // nh) ** -0.5, causal=causal), sd, p + "out_proj")
 
 
+def lm_adapter(adapters: Optional[Dict[str, Tensor]], idx: int, x: Tensor) -> Tensor:
+    """SpeechMixAdapter (ref:speechmix/model.py:196-222): every LM encoder / decoder layer's hidden-state output is
+    REPLACED by Sequential(LayerNorm(d), Linear(d, d/2), ReLU, Linear(d/2, d)) of it (a forward hook, no residual).
+    Adapter index = stack * layers_per_stack + layer, i.e. the value the reference's loop variables hold when each hook
+    is registered (its lambdas capture them late, so as written every hook runs the LAST adapter; the intended indexing
+    is restated here)."""
+    if adapters is None:
+        return x
+    p = f"adapters.{idx}."
+    h = layer_norm(x, adapters[p + "0.weight"], adapters[p + "0.bias"], 1e-5)
+    h = torch.relu(h @ adapters[p + "1.weight"].t() + adapters[p + "1.bias"])
+    return h @ adapters[p + "3.weight"].t() + adapters[p + "3.bias"]
+
+
 def bart_like_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Tensor],
-                      decoder_input_ids: Tensor, trace: Optional[dict] = None):
+                      decoder_input_ids: Tensor, trace: Optional[dict] = None, adapters=None):
     """BART (post-LN) and mBART (pre-LN + final LNs) forward, eval mode.
     TF:models/bart/modeling_bart.py:58-98 (learned positions, offset 2), 260-390 (layers), 507-549
     (encoder), 594-676 (decoder), 939-940 (head + final_logits_bias);
@@ -254,6 +268,7 @@ def bart_like_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optio
             x = ln(h, p + "self_attn_layer_norm")
             h = h + _bart_attn(sd, p + "self_attn.", x, x, cfg["encoder_attention_heads"])
             h = h + linear(act(linear(ln(h, p + "final_layer_norm"), sd, p + "fc1")), sd, p + "fc2")
+        h = lm_adapter(adapters, i, h)
     if pre_ln:
         h = ln(h, "model.encoder.layer_norm")
     enc = h
@@ -276,6 +291,7 @@ def bart_like_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optio
             y = y + _bart_attn(sd, p + "self_attn.", x, x, nh, causal=True)
             y = y + _bart_attn(sd, p + "encoder_attn.", ln(y, p + "encoder_attn_layer_norm"), enc, nh)
             y = y + linear(act(linear(ln(y, p + "final_layer_norm"), sd, p + "fc1")), sd, p + "fc2")
+        y = lm_adapter(adapters, cfg["encoder_layers"] + i, y)     # (index: both stacks of every named LM are equally deep)
     if pre_ln:
         y = ln(y, "model.decoder.layer_norm")
     if trace is not None:
@@ -312,7 +328,7 @@ def t5_position_bias(table: Tensor, q_len: int, k_len: int, bidirectional: bool,
 
 
 def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Tensor],
-               decoder_input_ids: Tensor, trace: Optional[dict] = None):
+               decoder_input_ids: Tensor, trace: Optional[dict] = None, adapters=None):
     """T5 forward, eval mode.  TF:models/t5/modeling_t5.py:50-94 (RMSNorm, FF), 176-369 (attention:
     no QK scaling, shared bucketed relative bias from block 0), 640-752 (stack), 1044-1054 (logit
     scale d_model^-0.5 when embeddings are tied)."""
@@ -349,6 +365,7 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
         x = rms_norm(h, sd[p + "layer.0.layer_norm.weight"], eps)
         h = h + attn(p + "layer.0.SelfAttention.", x, x, ebias, False)
         h = h + ff(p + "layer.1.DenseReluDense.", rms_norm(h, sd[p + "layer.1.layer_norm.weight"], eps))
+        h = lm_adapter(adapters, i, h)
     enc = rms_norm(h, sd["encoder.final_layer_norm.weight"], eps)
     if trace is not None:
         trace["lm_encoder_last_hidden"] = enc
@@ -364,6 +381,7 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
         x = rms_norm(y, sd[p + "layer.1.layer_norm.weight"], eps)
         y = y + attn(p + "layer.1.EncDecAttention.", x, enc, None, False)
         y = y + ff(p + "layer.2.DenseReluDense.", rms_norm(y, sd[p + "layer.2.layer_norm.weight"], eps))
+        y = lm_adapter(adapters, cfg["num_layers"] + i, y)
     y = rms_norm(y, sd["decoder.final_layer_norm.weight"], eps)
     if trace is not None:
         trace["decoder_last_hidden"] = y
@@ -375,13 +393,29 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
     return y @ head.t(), enc
 
 
-def lm_forward(sd, cfg, inputs_embeds=None, input_ids=None, decoder_input_ids=None, trace=None):
+def lm_forward(sd, cfg, inputs_embeds=None, input_ids=None, decoder_input_ids=None, trace=None, adapters=None):
     mt = cfg["model_type"]
     if mt in ("bart", "mbart"):
-        return bart_like_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace)
+        return bart_like_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace, adapters)
     if mt == "t5":
-        return t5_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace)
+        return t5_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace, adapters)
     raise ValueError(mt)
+
+
+def greedy_labels(lm_sd, cfg, gen_input, max_length: int, adapters=None):
+    """ref:train.py:18-34 `create_self_decoder_input`: greedy decoding of the LM on token ids, re-running the whole model
+    for every token (the reference's loop), at most max(max_length, len(input)) steps, stopping BEFORE an eos is appended.
+    -> predicted ids without the start token."""
+    predicted = [cfg["decoder_start_token_id"]]
+    ids = torch.tensor([list(gen_input)])
+    with torch.no_grad():
+        for _ in range(max(max_length, len(gen_input))):
+            logits, _ = lm_forward(lm_sd, cfg, input_ids=ids, decoder_input_ids=torch.tensor([predicted]), adapters=adapters)
+            nxt = int(logits.argmax(-1)[0, -1])
+            if nxt == cfg["eos_token_id"]:
+                break
+            predicted.append(nxt)
+    return predicted[1:]
 
 
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
@@ -452,7 +486,9 @@ def speechmix_eed_forward(sd: Dict[str, Tensor], enc_cfg: dict, lm_cfg: dict, in
         pe = lm_token_embedding(lm_sd, lm_cfg, prompt_ids)
         x = torch.cat((pe.expand(B, -1, -1), x), 1)
     out["inputs_embeds"] = x
-    logits, enc_last = lm_forward(lm_sd, lm_cfg, inputs_embeds=x, decoder_input_ids=decoder_input_ids, trace=trace)
+    adapters = {k: v for k, v in rest.items() if k.startswith("adapters.")} or None          # SpeechMixAdapter
+    logits, enc_last = lm_forward(lm_sd, lm_cfg, inputs_embeds=x, decoder_input_ids=decoder_input_ids, trace=trace,
+                                  adapters=adapters)
     out["lm_encoder_last_hidden"] = enc_last
     out["raw_logits"] = logits
     out["logits"] = logits.argmax(-1)

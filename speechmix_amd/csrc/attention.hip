@@ -21,7 +21,7 @@ struct SmxAttnParams {
     const float* bias;    // optional [H, Tq, Tk] fp32 additive bias
     const void* dO; void* dQ; void* dK; void* dV;   // backward only
     float* delta;         // [B, H, Tq] backward scratch: sum_d dO*O
-    float* dbias;         // optional [H, Tq, Tk] fp32, atomically accumulated (fp32 path only)
+    float* dbias;         // optional [H, Tq, Tk] fp32: += sum over the batch of dS (attn_dbias_kernel)
     long long q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld;       // element strides (batch, row)
     long long dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, do_bs, do_ld;
     int B, H, Tq, Tk, D;
@@ -127,7 +127,6 @@ __global__ void attn_bwd_dq_simple(SmxAttnParams p) {
         if (p.bias) s += p.bias[((long long)h * p.Tq + q) * p.Tk + k];
         if (p.drop_p > 0.f) dp *= ATT_DROP(p, b, h, q, k);
         const float ds = expf(s - lse) * (dp - delta);
-        if (p.dbias) atomicAdd(p.dbias + ((long long)h * p.Tq + q) * p.Tk + k, ds);
         for (int d = 0; d < p.D; ++d) dq[d] = fmaf(ds * p.scale, Cvt<T>::ld(K + k * p.k_ld + d), dq[d]);
     }
     T* dQ = reinterpret_cast<T*>(p.dQ) + b * p.dq_bs + q * p.dq_ld + h * p.D;
@@ -166,6 +165,54 @@ __global__ void attn_bwd_dkv_simple(SmxAttnParams p) {
     T* dK = reinterpret_cast<T*>(p.dK) + b * p.dk_bs + k * p.dk_ld + h * p.D;
     T* dV = reinterpret_cast<T*>(p.dV) + b * p.dv_bs + k * p.dv_ld + h * p.D;
     for (int d = 0; d < p.D; ++d) { Cvt<T>::st(dK + d, dk[d]); Cvt<T>::st(dV + d, dv[d]); }
+}
+
+// Gradient of the additive score bias (T5's relative-position bias, TF:models/t5/modeling_t5.py:216-279, 329-345):
+// dbias[h, q, k] += sum_b dS[b, h, q, k] with dS = P * (mask * dP - delta), S recomputed from the saved log-sum-exp.
+// One thread owns one (h, q, k): no atomics, deterministic.  Used by the MFMA path (whose dQ / dK/dV kernels do not
+// produce it); delta must have been written (the dQ kernel does).  The tables are tiny (T5 runs on S <= 249 keys).
+template <typename T>
+__global__ void attn_dbias_kernel(SmxAttnParams p) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)p.H * p.Tq * p.Tk) return;
+    const int k = (int)(idx % p.Tk), q = (int)((idx / p.Tk) % p.Tq), h = (int)(idx / ((long long)p.Tk * p.Tq));
+    if (p.causal && k > q + (p.Tk - p.Tq)) return;
+    const float bias = p.bias ? p.bias[idx] : 0.f;
+    float acc = 0.f;
+    for (int b = 0; b < p.B; ++b) {
+        const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
+        const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + q * p.do_ld + h * p.D;
+        const T* K = reinterpret_cast<const T*>(p.K) + b * p.k_bs + k * p.k_ld + h * p.D;
+        const T* V = reinterpret_cast<const T*>(p.V) + b * p.v_bs + k * p.v_ld + h * p.D;
+        float s = 0.f, dp = 0.f;
+        for (int d = 0; d < p.D; d += 8) {
+            float a[8], c[8], e[8], f[8];
+            load8(Q + d, a); load8(K + d, c); load8(dO + d, e); load8(V + d, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s = fmaf(a[j], c[j], s); dp = fmaf(e[j], f[j], dp); }
+        }
+        s = s * p.scale + bias;
+        if (p.drop_p > 0.f) dp *= ATT_DROP(p, b, h, q, k);
+        const long long li = ((long long)b * p.H + h) * p.Tq + q;
+        acc += expf(s - p.lse[li]) * (dp - p.delta[li]);
+    }
+    p.dbias[idx] += acc;
+}
+
+// dtable[bucket[q, k], h] += dbias[h, q, k]: one block per (bucket, head), fixed-order tree reduction (deterministic).
+__global__ void attn_bias_scatter_kernel(const float* dbias, const int* bucket, float* dtable, int H, int QK) {
+    const int bk = blockIdx.x, h = blockIdx.y;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < QK; i += blockDim.x)
+        if (bucket[i] == bk) acc += dbias[(long long)h * QK + i];
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dtable[bk * H + h] += red[0];
 }
 
 // ============================== bf16 MFMA kernels (D = 64) =======================================
@@ -711,18 +758,39 @@ extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t
         hipLaunchKernelGGL(attn_bwd_dq_simple<float>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
         const int nk = p.B * p.H * p.Tk;
         hipLaunchKernelGGL(attn_bwd_dkv_simple<float>, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
+        if (p.dbias) {
+            const long long nb = (long long)p.H * p.Tq * p.Tk;
+            hipLaunchKernelGGL(attn_dbias_kernel<float>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, p);
+        }
     } else if (dtype == SMX_BF16 && p.D != 64) {
         hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(attn_bwd_dq_simple<bf16_t>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
         const int nk = p.B * p.H * p.Tk;
         hipLaunchKernelGGL(attn_bwd_dkv_simple<bf16_t>, dim3((nk + 63) / 64), dim3(64), 0, stream, p);
+        if (p.dbias) {
+            const long long nb = (long long)p.H * p.Tq * p.Tk;
+            hipLaunchKernelGGL(attn_dbias_kernel<bf16_t>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, p);
+        }
     } else if (dtype == SMX_BF16) {
-        if (p.dbias) return SMX_EINVAL;
         if (!p.O) return SMX_EINVAL;
         // dQ also writes delta = rowsum(dO * O); the dK/dV kernel reads it (stream order)
         hipLaunchKernelGGL(attn_bwd_dq_bf16<1>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
         hipLaunchKernelGGL(attn_bwd_dkv_bf16<1>, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        if (p.dbias) {
+            const long long nb = (long long)p.H * p.Tq * p.Tk;
+            hipLaunchKernelGGL(attn_dbias_kernel<bf16_t>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, p);
+        }
     } else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// T5 relative-position bias: scatter-add the [H, Tq, Tk] score-bias gradient into the [buckets, H] table
+// (TF:models/t5/modeling_t5.py:261-279: values = relative_attention_bias(bucket) -> permute).  bucket: int32 [Tq*Tk].
+extern "C" int smx_attn_bias_scatter(const float* dbias, const int* bucket, float* dtable, int H, int Tq, int Tk, int nbuckets,
+                                     hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!dbias || !bucket || !dtable || H <= 0 || Tq <= 0 || Tk <= 0 || nbuckets <= 0) return SMX_EINVAL;
+    hipLaunchKernelGGL(attn_bias_scatter_kernel, dim3(nbuckets, H), dim3(256), 0, stream, dbias, bucket, dtable, H, Tq * Tk);
     SMX_CHECK_LAUNCH();
 }
 

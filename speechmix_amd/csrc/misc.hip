@@ -615,9 +615,11 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ p
         const int m = i / cv, c = (i % cv) * 8;
         float d[8], x[8];
         load8(dy + (long long)m * N + c, d);
-        load8(pre + (long long)m * N + c, x);
+        if (pre) {                                   // pre == null: plain copy of dy through the output view
+            load8(pre + (long long)m * N + c, x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] *= act_grad(x[e], act);   // (scalar form: this kernel is HBM-bound)
+            for (int e = 0; e < 8; ++e) d[e] *= act_grad(x[e], act);   // (scalar form: this kernel is HBM-bound)
+        }
         store8(dx + view_off(ov, m) + c, d);
     }
 }

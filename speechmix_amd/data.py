@@ -57,10 +57,60 @@ class DataCollatorWithPadding:
         return batch
 
 
+def filter_by_length(lengths, max_input_length_in_sec, min_input_length_in_sec=1, sample_rate=16000):
+    """Indices of the clips the reference keeps (ref:train.py:276-286): min * 16000 < samples < max * 16000, strict."""
+    lo, hi = min_input_length_in_sec * sample_rate, max_input_length_in_sec * sample_rate
+    return [i for i, n in enumerate(lengths) if lo < n < hi]
+
+
+def length_grouped_indices(lengths, batch_size, mega_batch_mult=None, generator=None):
+    """Order of the training set under the reference's `--group_by_length` (ref:train.py:176, 297 -> HF Trainer's
+    LengthGroupedSampler, TF:trainer_pt_utils.py get_length_grouped_indices): a random permutation cut into mega-batches of
+    `mega_batch_mult * batch_size` clips, each sorted by length (longest first), with the globally longest clip moved to
+    the front (so an out-of-memory shows on step 1).  Consecutive `batch_size` slices are then batches of near-equal
+    length: the -100 padding of the collator - which the speech encoder convolves like audio - stays minimal, and a rank's
+    batch shapes repeat, so workspaces and kernel choices are reused."""
+    n = len(lengths)
+    if mega_batch_mult is None:
+        mega_batch_mult = min(n // (batch_size * 4), 50) or 1
+    perm = torch.randperm(n, generator=generator).tolist()
+    mb = mega_batch_mult * batch_size
+    megas = [sorted(perm[i:i + mb], key=lambda j: lengths[j], reverse=True) for i in range(0, n, mb)]
+    if megas:
+        k = max(range(len(megas)), key=lambda j: lengths[megas[j][0]])
+        megas[0][0], megas[k][0] = megas[k][0], megas[0][0]
+    return [j for m in megas for j in m]
+
+
+def bucketed_batches(dataset, collator, batch_size, lengths=None, group_by_length=True, generator=None, drop_last=False,
+                     rank=0, world=1):
+    """Collated batches of one epoch for this rank: length-grouped order (or a plain permutation), cut into global batches
+    of `batch_size * world` clips of which rank r takes the r-th slice (data parallel: each clip is independent)."""
+    n = len(dataset)
+    if lengths is None:
+        lengths = [len(dataset[i]["input_values"]) for i in range(n)]
+    order = length_grouped_indices(lengths, batch_size * world, generator=generator) if group_by_length \
+        else torch.randperm(n, generator=generator).tolist()
+    gb = batch_size * world
+    for i in range(0, n, gb):
+        idx = order[i:i + gb]
+        if len(idx) < gb and (drop_last or world > 1):
+            break
+        mine = idx[rank * batch_size:(rank + 1) * batch_size]
+        yield collator([dataset[j] for j in mine])
+
+
 class DevicePrefetcher:
     """Wraps an iterable of collated batches: each batch is staged in pinned host memory and copied to the device on a
     side stream while the previous step computes (the 20.5-MB waveform batch of config 2 is <1 % of a step over PCIe,
     DESIGN.md §6 - this hides it completely)."""
+
+    @classmethod
+    def from_dataset(cls, dataset, collator, batch_size, device, lengths=None, group_by_length=True, generator=None,
+                     rank=0, world=1):
+        """Length-bucketed epoch (see `bucketed_batches`) behind the prefetcher."""
+        return cls(bucketed_batches(dataset, collator, batch_size, lengths, group_by_length, generator, rank=rank,
+                                    world=world), device)
 
     def __init__(self, batches: Iterable[Dict[str, torch.Tensor]], device):
         self.it, self.device = iter(batches), torch.device(device)

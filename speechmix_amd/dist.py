@@ -17,16 +17,19 @@ import torch
 import torch.distributed as dist
 
 
-def stage_ranges(offsets: Dict[str, Tuple[int, int, tuple]], num_speech_layers: int, max_bucket_elems: int = 64 << 20):
-    """Contiguous flat ranges per backward stage, in the order backward completes them."""
+def stage_ranges(offsets: Dict[str, Tuple[int, int, tuple]], num_speech_layers: int, max_bucket_elems: int = 64 << 20,
+                 trainable=None):
+    """Contiguous flat ranges per backward stage, in the order backward completes them.  trainable(name) -> bool: only
+    parameters that can receive a gradient are reduced (the flags are the same on every rank, so the bucket list is too; a
+    frozen LM - SpeechMixSelf / SpeechMixFixed - would otherwise all-reduce ~560 MB of zeros per step)."""
     def span(pred):
-        sel = [(o, o + n) for name, (o, n, _) in offsets.items() if pred(name)]
+        sel = [(o, o + n) for name, (o, n, _) in offsets.items() if pred(name) and (trainable is None or trainable(name))]
         if not sel:
             return []
         sel.sort()
         out = [list(sel[0])]
         for a, b in sel[1:]:
-            if a - out[-1][1] <= 4096:       # merge across alignment padding
+            if a - out[-1][1] <= 64:         # merge across alignment padding (FlatStore.ALIGN), never across a frozen tensor
                 out[-1][1] = max(out[-1][1], b)
             else:
                 out.append([a, b])
@@ -38,7 +41,7 @@ def stage_ranges(offsets: Dict[str, Tuple[int, int, tuple]], num_speech_layers: 
             chunks.append((a, b))
         return chunks
 
-    stages = [("lm", span(lambda n: n.startswith("decoder_model.")))]
+    stages = [("lm", span(lambda n: n.startswith(("decoder_model.", "adapters."))))]
     stages.append(("bridge", span(lambda n: n.startswith(("length_adapters.", "enc_to_dec_proj.", "weights_sum")))))
     for i in range(num_speech_layers - 1, -1, -1):
         pre = f"encoder_model.encoder.layers.{i}."
@@ -56,6 +59,7 @@ class GradReducer:
         self.order = [s for s, _ in stages]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force_comm = force_comm
         self.active = self.world > 1 or (force_comm and dist.is_initialized())
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda and self.active else None

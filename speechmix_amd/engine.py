@@ -52,6 +52,7 @@ class Engine:
         self.rng = np.random.default_rng(rank)
         self.drop_rng = np.random.default_rng(0x5eed + rank)   # per-site dropout seeds (masks are regenerated in backward)
         self.stage_cb = None      # callable(stage_name): gradient ranges of that stage are final (dist.GradReducer)
+        self.lm_adapters = store.has_prefix("adapters.")      # SpeechMixAdapter: bottleneck adapters behind every LM layer
 
     def _dp(self, p):
         """(p, fresh 32-bit seed) for one dropout site, or None when the site is inactive."""
@@ -171,6 +172,13 @@ class Engine:
                    resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
         return dx
 
+    def _slab_key(self):
+        """Grow-only slab workspace, one per stream: a buffer that grows is replaced, and the replaced tensor must not go back
+        to the allocator of one stream while kernels queued on the other still write it."""
+        side = getattr(self, "_side", None)
+        on_side = side is not None and torch.cuda.current_stream() == side
+        return "wgrad_slabs_side" if on_side else "wgrad_slabs"
+
     def _wgrad_gemm(self, dy, x, out, No, Ko, Kred, av, bv, alpha, accumulate, cv=None, **kw):
         """out[No,Ko] (+)= dy^T x over Kred rows.  Two candidate launches - the 128x128 kernel with its K split and the
         ping-pong kernel with a split sized for one round of 256x256 items - timed on first use per shape (both write
@@ -189,7 +197,7 @@ class Engine:
                 ops.gemm(dy, x, out, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True,
                          atomic=2 if accumulate else 0, alpha=alpha, tr_mode=mode, **kw)
                 return
-            slabs = self.workspace("wgrad_slabs", split * n, torch.float32)
+            slabs = self.workspace(self._slab_key(), split * n, torch.float32)
             ops.gemm(dy, x, slabs, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True, atomic=0,
                      split_k=split, split_stride=n, alpha=alpha, tr_mode=mode, **kw)
             ops.reduce_slabs(slabs, split, n, n, out, accumulate=accumulate)
@@ -203,7 +211,7 @@ class Engine:
                 if all(sp > 1 for _, sp in cands):          # slab launches only: re-running them changes nothing
                     ts = []
                     for mode, sp in cands:
-                        slabs = self.workspace("wgrad_slabs", sp * n, torch.float32)
+                        slabs = self.workspace(self._slab_key(), sp * n, torch.float32)
 
                         def once():
                             ops.gemm(dy, x, slabs, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True,
@@ -305,9 +313,10 @@ class Engine:
         ops.attention_fwd(desc, lse, self.dt)
         return o, dict(x=x, kvsrc=kvsrc, qkv=qkv, kv=kv, o=o, lse=lse, desc=desc, dims=(B, Tq, Tk, d, H))
 
-    def attn_bwd(self, do, sv, names, dx_resid=None, dkv_accum=None, dx=None):
+    def attn_bwd(self, do, sv, names, dx_resid=None, dkv_accum=None, dx=None, dbias=None):
         """do: grad wrt attention output o (before out_proj).  Returns dx (grad wrt x, + dx_resid).
-        Cross attention: grad wrt kvsrc is accumulated into dkv_accum [B*Tk, d] (must be pre-initialised)."""
+        Cross attention: grad wrt kvsrc is accumulated into dkv_accum [B*Tk, d] (must be pre-initialised).
+        dbias [H, Tq, Tk] fp32: += the batch-summed score gradient (T5 relative-position bias)."""
         B, Tq, Tk, d, H = sv["dims"]
         Mq, Mk = B * Tq, B * Tk
         desc = sv["desc"]
@@ -319,7 +328,7 @@ class Engine:
             desc.set("dQ", dqkv, 0, Tq * 3 * d, 3 * d)
             desc.set("dK", dqkv, d, Tk * 3 * d, 3 * d)
             desc.set("dV", dqkv, 2 * d, Tk * 3 * d, 3 * d)
-            ops.attention_bwd(desc, sv["lse"], delta, self.dt)
+            ops.attention_bwd(desc, sv["lse"], delta, self.dt, dbias=dbias)
             wn = [qn[0], kn[0], vn[0]]
             if self.tr(*wn):
                 self.wgrad(dqkv, sv["x"], self.st.cat(wn, "g"), Mq, 3 * d, d,
@@ -424,7 +433,7 @@ class Engine:
         self.dgrad(dy, self.W(wn), do, M, d, d)
         return do
 
-    def layer_bwd(self, dy, sv, nm, pre_ln, act, rms=False, denc=None):
+    def layer_bwd(self, dy, sv, nm, pre_ln, act, rms=False, denc=None, dbias=None):
         B, T, d, H, F = sv["dims"]
         M = B * T
         if not pre_ln:
@@ -436,7 +445,7 @@ class Engine:
                 dh = self.attn_bwd(do2, sv["x"], nm["xattn"], dx_resid=ds2, dkv_accum=denc)
             ds1 = self.ln_bwd(dh, sv["ln1"], nm["ln1"][0], nm["ln1"][1], M, d)
             do = self._oproj_bwd(ds1, sv["a"], nm["attn"], M, d, sv["d_o"])
-            return self.attn_bwd(do, sv["a"], nm["attn"], dx_resid=ds1)
+            return self.attn_bwd(do, sv["a"], nm["attn"], dx_resid=ds1, dbias=dbias)
         # pre-LN: y = x1 + ffn(LN2(x1)); x1 = x(+cross) + attn(LN1(x))
         dn2 = self._ffn_bwd(dy, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, None)
         dx1 = self.ln_bwd(dn2, sv["ln2"], nm["ln2"][0], nm["ln2"][1] if not rms else None, M, d, rms=rms, dres=dy)
@@ -445,8 +454,27 @@ class Engine:
             dnx = self.attn_bwd(do2, sv["x"], nm["xattn"], dkv_accum=denc)
             dx1 = self.ln_bwd(dnx, sv["lnx"], nm["lnx"][0], nm["lnx"][1] if not rms else None, M, d, rms=rms, dres=dx1)
         do = self._oproj_bwd(dx1, sv["a"], nm["attn"], M, d, sv["d_o"])
-        dn1 = self.attn_bwd(do, sv["a"], nm["attn"])
+        dn1 = self.attn_bwd(do, sv["a"], nm["attn"], dbias=dbias)
         return self.ln_bwd(dn1, sv["ln1"], nm["ln1"][0], nm["ln1"][1] if not rms else None, M, d, rms=rms, dres=dx1)
+
+    # ------------------------------------------------------------------ SpeechMixAdapter (ref:speechmix/model.py:196-222)
+    def _adapter_names(self, idx):
+        p = f"adapters.{idx}."
+        return (p + "0.weight", p + "0.bias"), (p + "1.weight", p + "1.bias"), (p + "3.weight", p + "3.bias")
+
+    def adapter_fwd(self, x, idx, M, d):
+        """Layer output -> Linear(ReLU(Linear(LayerNorm(x)))), bottleneck d/2, no residual (the reference's forward hook
+        replaces the layer's hidden-state output)."""
+        ln, n1, n2 = self._adapter_names(idx)
+        n, lnsv = self.ln_fwd(x, ln[0], ln[1], M, d, 1e-5)
+        y, fsv = self._ffn_fwd(n, M, d, d // 2, n1, n2, ACT_RELU, None)
+        return y, (lnsv, fsv)
+
+    def adapter_bwd(self, dy, sv, idx, M, d):
+        ln, n1, n2 = self._adapter_names(idx)
+        lnsv, fsv = sv
+        dn = self._ffn_bwd(dy, fsv, M, d, d // 2, n1, n2, ACT_RELU, None)
+        return self.ln_bwd(dn, lnsv, ln[0], ln[1], M, d)
 
     # ------------------------------------------------------------------ name tables
     def _w2v2_layer_names(self, i):
@@ -565,7 +593,7 @@ class Engine:
         else:
             p = f"{ep}feature_extractor.conv_layers.{i}."
             tmp = self.ln_bwd(dfeat, sv["ln"][i], p + "layer_norm.weight", p + "layer_norm.bias", B * Ti, Ci, act=ACT_GELU)
-            dpre.view(B, Ti + 2 * PAD, Ci)[:, PAD:PAD + Ti].copy_(tmp.view(B, Ti, Ci))
+            ops.act_bwd(tmp, None, dpre, B * Ti, Ci, padv, ACT_NONE, self.dt)        # rows into the padded per-clip buffer
         for i in range(nl - 1, 0, -1):
             p = f"{ep}feature_extractor.conv_layers.{i}."
             Co, Cin, k, s = ec.conv_dim[i], ec.conv_dim[i - 1], ec.conv_kernel[i], ec.conv_stride[i]
@@ -594,9 +622,8 @@ class Engine:
                 U = (Tin - 1 - r) // s + 1 if Tin - 1 - r >= 0 else 0
                 if U <= 0:
                     continue
-                if nj == 0:
-                    dprev.view(B, -1, Cin)[:, (prev_off // Cin) + r:(prev_off // Cin) + Tin:s].zero_()
-                    continue
+                if nj == 0:          # stride > kernel: no feature extractor on the path has it (k >= s in every config)
+                    raise NotImplementedError("conv layer with stride > kernel size")
                 av = view(Co, U, Tp * Co, (PAD - (nj - 1)) * Co)
                 bv = view(k * Cin, Co, -s * Cin, (r + (nj - 1) * s) * Cin)
                 cv = view(s * Cin, U, prev_bs, prev_off + r * Cin)
@@ -610,7 +637,7 @@ class Engine:
                                   act=ACT_GELU)
                 Tpp = Tin + 2 * PAD
                 dprev = self.persist_zeros(f"cnn_dpre{i - 1}", B * Tpp, Cin)
-                dprev.view(B, Tpp, Cin)[:, PAD:PAD + Tin].copy_(tmp.view(B, Tin, Cin))
+                ops.act_bwd(tmp, None, dprev, B * Tin, Cin, view(Cin, Tin, Tpp * Cin, PAD * Cin), ACT_NONE, self.dt)
             dpre = dprev
         # layer 0
         p0 = f"{ep}feature_extractor.conv_layers.0."
@@ -834,6 +861,35 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ seq2seq LM
+    def _check_positions(self, S=0, Ld=0):
+        """BART / mBART learned positions (TF:models/bart/modeling_bart.py:74-98: rows 2 + arange(T) of a
+        [max_position_embeddings + 2, d] table).  HF raises IndexError past the table; the kernels index it unchecked
+        (and in backward add into it), so the bound is enforced here, on the host, before any launch."""
+        lp = self.lp
+        for side, T in (("encoder", S), ("decoder", Ld)):
+            name = f"{lp}model.{side}.embed_positions.weight"
+            if T and self.has(name):
+                rows = self.st.offsets[name][2][0]
+                if T + 2 > rows:
+                    raise IndexError(f"{side} sequence of {T} positions needs {T + 2} rows of {name}, which has {rows} "
+                                     f"(max_position_embeddings = {rows - 2}): index out of range in self")
+
+    def _check_ids(self, ids, V, what, allow_ignore=False):
+        """Token ids must lie in [0, V) (labels: or equal -100).  Free for host tensors; device tensors are checked only
+        with SMX_CHECK_IDS=1 (the reduction forces a device sync)."""
+        if ids is None or (ids.is_cuda and os.environ.get("SMX_CHECK_IDS") != "1"):
+            return
+        if ids.numel() == 0:
+            return
+        x = ids
+        if allow_ignore:
+            x = x[x != -100]
+            if x.numel() == 0:
+                return
+        lo, hi = int(x.min()), int(x.max())
+        if lo < 0 or hi >= V:
+            raise IndexError(f"{what}: token id out of range [0, {V}) (min {lo}, max {hi})")
+
     def _t5_bias(self, side, Tq, Tk):
         """Relative-position bias [H, Tq, Tk] fp32 (TF:models/t5/modeling_t5.py:216-279).  Bucket indices are
         integer host work; the gather from the [buckets, H] table is a pure index op."""
@@ -859,6 +915,12 @@ class Engine:
         buckets = (ret + torch.where(small, rel, large)).to(self.dev)
         table = self.P(name)                                   # [buckets, H] fp32
         return table[buckets].permute(2, 0, 1).contiguous(), buckets
+
+    def _t5_bias_bwd(self, entry, buckets):
+        tname, dbias, T = entry
+        H = dbias.shape[0]
+        ops.attn_bias_scatter(dbias, buckets.reshape(-1).to(torch.int32).contiguous(), self.G(tname), H, T, T,
+                              self.lc.relative_attention_num_buckets)
 
     def lm_fwd(self, inputs_embeds, input_ids, dec_ids, B, S, Ld, training):
         lc, lp = self.lc, self.lp
@@ -887,14 +949,16 @@ class Engine:
         if t5:
             if lc.is_gated_act:
                 raise NotImplementedError("gated T5 feed-forward is not on the SpeechMix path")
-            ebias, _ = self._t5_bias("encoder", S, S)
-            dbias, _ = self._t5_bias("decoder", Ld, Ld)
+            ebias, eb = self._t5_bias("encoder", S, S)
+            dbias, db = self._t5_bias("decoder", Ld, Ld)
+            sv["t5_buckets"] = (eb, db)
             sv["d_enc_in"] = self._dp(pdrop)
             h = self._dropped(x, sv["d_enc_in"], B * S * d)
             eps = lc.layer_norm_epsilon
         else:
             eps = 1e-5
             pe = lp + "model.encoder."
+            self._check_positions(S, Ld)
             h, sv["enc_emb_ln"] = self.ln_fwd(x, pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", B * S, d,
                                               eps, pos=self.W(pe + "embed_positions.weight"), pos_period=S, pos_offset=2,
                                               want_sum=True, drop=self._dp(pdrop))
@@ -903,6 +967,8 @@ class Engine:
             nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
             h, lsv = self.layer_fwd(h, B, S, d, H, F, nm, pre_ln, act, eps, scale=1.0 if t5 else None, rms=t5, bias=ebias,
                                     drop=drop)
+            if self.lm_adapters:
+                h, lsv["adapter"] = self.adapter_fwd(h, i, B * S, d)
             sv["enc_layers"].append(lsv)
         if t5:
             h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "encoder.final_layer_norm.weight", None, B * S, d, eps, rms=True,
@@ -930,6 +996,8 @@ class Engine:
             nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
             y, lsv = self.layer_fwd(y, B, Ld, d, Hd, Fd, nm, pre_ln, act, eps, causal=True, scale=1.0 if t5 else None,
                                     enc=enc, Tk=S, rms=t5, bias=dbias, drop=drop)
+            if self.lm_adapters:
+                y, lsv["adapter"] = self.adapter_fwd(y, lc.encoder_layers + i, B * Ld, d)
             sv["dec_layers"].append(lsv)
         if t5:
             y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "decoder.final_layer_norm.weight", None, B * Ld, d, eps, rms=True,
@@ -957,24 +1025,38 @@ class Engine:
         lc, lp = self.lc, self.lp
         d = lc.d_model
         t5 = lc.model_type == "t5"
-        if t5:
-            raise NotImplementedError("cached greedy decoding: BART / mBART decoders only (T5's relative bias is not wired)")
-        pre_ln = lc.model_type == "mbart"
+        pre_ln = lc.model_type in ("mbart", "t5")
         act = _act_id(lc.activation_function)
-        emb_name = lp + "model.shared.weight"
-        escale = math.sqrt(d) if lc.scale_embedding else 1.0
+        emb_name = lp + ("shared.weight" if t5 else "model.shared.weight")
+        escale = math.sqrt(d) if (lc.scale_embedding and not t5) else 1.0
         if inputs_embeds is None:
             x = self.new(B * S, d)
             ops.embed_fwd(input_ids, self.W(emb_name), x, B * S, d, escale, self.dt)
         else:
             x = inputs_embeds
+        if t5:
+            if lc.is_gated_act:
+                raise NotImplementedError("gated T5 feed-forward is not on the SpeechMix path")
+            eps = lc.layer_norm_epsilon
+            ebias, _ = self._t5_bias("encoder", S, S)
+            h = x
+            for i in range(lc.encoder_layers):
+                h, _ = self.layer_fwd(h, B, S, d, lc.encoder_attention_heads, lc.encoder_ffn_dim,
+                                      self._t5_layer_names("encoder", i), True, act, eps, scale=1.0, rms=True, bias=ebias)
+                if self.lm_adapters:
+                    h, _ = self.adapter_fwd(h, i, B * S, d)
+            h, _ = self.ln_fwd(h, lp + "encoder.final_layer_norm.weight", None, B * S, d, eps, rms=True)
+            return h
         eps = 1e-5
         pe = lp + "model.encoder."
+        self._check_positions(S=S)
         h, _ = self.ln_fwd(x, pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", B * S, d, eps,
                            pos=self.W(pe + "embed_positions.weight"), pos_period=S, pos_offset=2, want_sum=True)
         for i in range(lc.encoder_layers):
             h, _ = self.layer_fwd(h, B, S, d, lc.encoder_attention_heads, lc.encoder_ffn_dim, self._bart_layer_names("encoder", i),
                                   pre_ln, act, eps)
+            if self.lm_adapters:
+                h, _ = self.adapter_fwd(h, i, B * S, d)
         if pre_ln:
             h, _ = self.ln_fwd(h, pe + "layer_norm.weight", pe + "layer_norm.bias", B * S, d, eps)
         return h
@@ -984,31 +1066,45 @@ class Engine:
         projected once, every step projects ONE new token per clip (its K/V land in the cache through the GEMM's output
         view), attends over the cached prefix and takes the arg-max of the LM head.  Replaces the reference's loops that
         re-run the whole decoder - and in the notebook the whole speech encoder - per token (ref:train.py:18-34,
-        ref:eval.ipynb cell 6).  Returns int64 [B, n] generated ids (without the start token; rows that hit eos are padded
-        with pad_id after it) and the number of steps run.  forced [B, n] int64: feed these tokens instead of the arg-max
-        (scoring a given continuation through the cached path); keep_logits: list that receives each step's [B, V] logits."""
+        ref:eval.ipynb cell 6).  BART / mBART (learned positions, LayerNorm, biases) and T5 (RMSNorm, no biases, unscaled
+        scores + the decoder's relative-position bias row of the current step, TF:models/t5/modeling_t5.py:216-279,
+        logits x d^-0.5 when the head is tied).  Returns int64 [B, n] generated ids (without the start token; rows that
+        hit eos are padded with pad_id after it) and the number of steps run.  forced [B, n] int64: feed these tokens
+        instead of the arg-max (scoring a given continuation through the cached path); keep_logits: list that receives
+        each step's [B, V] logits."""
         lc, lp = self.lc, self.lp
-        if lc.model_type == "t5":
-            raise NotImplementedError("cached greedy decoding: BART / mBART decoders only")
+        t5 = lc.model_type == "t5"
         d, H, F = lc.d_model, lc.decoder_attention_heads, lc.decoder_ffn_dim
-        pre_ln = lc.model_type == "mbart"
+        pre_ln = lc.model_type in ("mbart", "t5")
         act = _act_id(lc.activation_function)
-        eps, scale = 1e-5, (d // H) ** -0.5
-        emb_name = lp + "model.shared.weight"
-        escale = math.sqrt(d) if lc.scale_embedding else 1.0
+        hd = (lc.d_kv if t5 else d // H)
+        inner = H * hd                                   # == d for every model on the path (T5: heads x d_kv)
+        if inner != d:
+            raise NotImplementedError("cached decoding assumes num_heads * d_kv == d_model")
+        eps = lc.layer_norm_epsilon if t5 else 1e-5
+        scale = 1.0 if t5 else hd ** -0.5
+        emb_name = lp + ("shared.weight" if t5 else "model.shared.weight")
+        escale = math.sqrt(d) if (lc.scale_embedding and not t5) else 1.0
         pd = lp + "model.decoder."
         Lmax = max_new_tokens
-        names = [self._bart_layer_names("decoder", i) for i in range(lc.decoder_layers)]
+        if not t5:
+            self._check_positions(Ld=Lmax)
+        names = [(self._t5_layer_names if t5 else self._bart_layer_names)("decoder", i) for i in range(lc.decoder_layers)]
+
+        def cat_b(pair_a, pair_b):
+            return self.st.cat([pair_a[1], pair_b[1]], "p32") if pair_a[1] else None
         # cross-attention K/V of every layer, once
         xkv = []
         for nm in names:
             kn, vn = nm["xattn"]["k"], nm["xattn"]["v"]
-            xkv.append(self.lin(enc, self.st.cat([kn[0], vn[0]]), self.st.cat([kn[1], vn[1]], "p32"), B * S, 2 * d, d))
+            xkv.append(self.lin(enc, self.st.cat([kn[0], vn[0]]), cat_b(kn, vn), B * S, 2 * d, d))
         cache = [self.zeros(B, Lmax, 2 * d) for _ in names]            # self-attention K | V per position
         V = lc.vocab_size
         Vp = (V + 7) // 8 * 8
         head = lp + "lm_head.weight" if self.has(lp + "lm_head.weight") else emb_name
-        flb = self.st.module.get_buffer(lp + "final_logits_bias").view(-1)
+        flb = self.st.module.get_buffer(lp + "final_logits_bias").view(-1) if not t5 else None
+        head_alpha = d ** -0.5 if (t5 and lc.tie_word_embeddings) else 1.0
+        pbias = self._t5_bias("decoder", Lmax, Lmax)[0] if t5 else None          # [H, Lmax, Lmax]: row t = step t's bias
         logits = self.new(B, Vp, dt=torch.float32)
         tok = torch.full((B,), start_id, dtype=torch.int64, device=self.dev)
         nxt = torch.empty(B, dtype=torch.int64, device=self.dev)
@@ -1019,12 +1115,14 @@ class Engine:
         for t in range(Lmax):
             y = self.new(B, d)
             ops.embed_fwd(tok, self.W(emb_name), y, B, d, escale, self.dt)
-            y, _ = self.ln_fwd(y, pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", B, d, eps,
-                               pos=self.W(pd + "embed_positions.weight"), pos_period=1, pos_offset=2 + t, want_sum=True)
+            if not t5:
+                y, _ = self.ln_fwd(y, pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", B, d, eps,
+                                   pos=self.W(pd + "embed_positions.weight"), pos_period=1, pos_offset=2 + t, want_sum=True)
+            sbias = pbias[:, t, :t + 1].contiguous() if t5 else None          # [H, 1, t+1]
             for li, nm in enumerate(names):
-                def attend(xq, wq, bq, kbuf, k_bs, k_ld, Tk):
-                    q = self.lin(xq, self.W(wq), self.P(bq), B, d, d)
-                    desc = ops.AttnDesc(B, H, 1, Tk, d // H, False, scale)
+                def attend(xq, wq, bq, kbuf, k_bs, k_ld, Tk, bias=None):
+                    q = self.lin(xq, self.W(wq), self._b(bq), B, d, d)
+                    desc = ops.AttnDesc(B, H, 1, Tk, hd, False, scale, bias)
                     desc.set("Q", q, 0, d, d)
                     desc.set("K", kbuf, 0, k_bs, k_ld)
                     desc.set("V", kbuf, d, k_bs, k_ld)
@@ -1034,15 +1132,15 @@ class Engine:
                     return o
                 a = nm["attn"]
                 x0 = y
-                xin = self.ln_fwd(x0, nm["ln1"][0], nm["ln1"][1], B, d, eps)[0] if pre_ln else x0
+                xin = self.ln_fwd(x0, nm["ln1"][0], nm["ln1"][1], B, d, eps, rms=t5)[0] if pre_ln else x0
                 # this token's K | V straight into the cache row t of every clip
-                self.lin(xin, self.st.cat([a["k"][0], a["v"][0]]), self.st.cat([a["k"][1], a["v"][1]], "p32"), B, 2 * d, d,
+                self.lin(xin, self.st.cat([a["k"][0], a["v"][0]]), cat_b(a["k"], a["v"]), B, 2 * d, d,
                          y=cache[li], cv=view(Lmax * 2 * d, 0, 0, t * 2 * d))
-                o = attend(xin, a["q"][0], a["q"][1], cache[li], Lmax * 2 * d, 2 * d, t + 1)
+                o = attend(xin, a["q"][0], a["q"][1], cache[li], Lmax * 2 * d, 2 * d, t + 1, sbias)
                 s1 = self.lin(o, self.W(a["o"][0]), self._b(a["o"][1]), B, d, d, resid=x0)
                 if pre_ln:
                     h = s1
-                    xin2 = self.ln_fwd(h, nm["lnx"][0], nm["lnx"][1], B, d, eps)[0]
+                    xin2 = self.ln_fwd(h, nm["lnx"][0], nm["lnx"][1], B, d, eps, rms=t5)[0]
                 else:
                     h = self.ln_fwd(s1, nm["ln1"][0], nm["ln1"][1], B, d, eps)[0]
                     xin2 = h
@@ -1050,15 +1148,19 @@ class Engine:
                 o2 = attend(xin2, xa["q"][0], xa["q"][1], xkv[li], S * 2 * d, 2 * d, S)
                 s2 = self.lin(o2, self.W(xa["o"][0]), self._b(xa["o"][1]), B, d, d, resid=h)
                 if pre_ln:
-                    n2 = self.ln_fwd(s2, nm["ln2"][0], nm["ln2"][1], B, d, eps)[0]
+                    n2 = self.ln_fwd(s2, nm["ln2"][0], nm["ln2"][1], B, d, eps, rms=t5)[0]
                     y, _ = self._ffn_fwd(n2, B, d, F, nm["fc1"], nm["fc2"], act, s2)
                 else:
                     h2 = self.ln_fwd(s2, nm["lnx"][0], nm["lnx"][1], B, d, eps)[0]
                     s3, _ = self._ffn_fwd(h2, B, d, F, nm["fc1"], nm["fc2"], act, h2)
                     y = self.ln_fwd(s3, nm["ln2"][0], nm["ln2"][1], B, d, eps)[0]
-            if pre_ln:
+                if self.lm_adapters:
+                    y, _ = self.adapter_fwd(y, lc.encoder_layers + li, B, d)
+            if t5:
+                y = self.ln_fwd(y, lp + "decoder.final_layer_norm.weight", None, B, d, eps, rms=True)[0]
+            elif pre_ln:
                 y = self.ln_fwd(y, pd + "layer_norm.weight", pd + "layer_norm.bias", B, d, eps)[0]
-            ops.gemm(y, self.W(head), logits, B, V, d, self.dt, cv=view(Vp), bias=flb, out_f32=True)
+            ops.gemm(y, self.W(head), logits, B, V, d, self.dt, cv=view(Vp), bias=flb, out_f32=True, alpha=head_alpha)
             ops.cross_entropy(logits, None, None, nxt, None, B, V, Vp, Vp, self.dt)
             steps += 1
             if keep_logits is not None:
@@ -1134,10 +1236,23 @@ class Engine:
             dy = self.ln_bwd(dy, sv["dec_final_ln"], lp + "model.decoder.layer_norm.weight", lp + "model.decoder.layer_norm.bias",
                              Md, d)
         denc = [self.new(Ms, d), True]
+        # T5: every layer of a stack adds the stack's relative-position bias (owned by block 0) to its self-attention
+        # scores, so the table's gradient is the scatter of the score gradients summed over batch AND layers
+        tb = {}
+        if t5:
+            for side, T in (("encoder", S), ("decoder", Ld)):
+                tname = f"{lp}{side}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"
+                if self.tr(tname):
+                    tb[side] = (tname, self.zeros(lc.encoder_attention_heads, T, T, dt=torch.float32), T)
         for i in range(lc.decoder_layers - 1, -1, -1):
             nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
-            dy = self.layer_bwd(dy, sv["dec_layers"][i], nm, pre_ln, act, rms=t5, denc=denc)
+            if "adapter" in sv["dec_layers"][i]:
+                dy = self.adapter_bwd(dy, sv["dec_layers"][i]["adapter"], lc.encoder_layers + i, Md, d)
+            dy = self.layer_bwd(dy, sv["dec_layers"][i], nm, pre_ln, act, rms=t5, denc=denc,
+                                dbias=tb["decoder"][1] if "decoder" in tb else None)
             denc[1] = False
+        if "decoder" in tb:
+            self._t5_bias_bwd(tb["decoder"], sv["t5_buckets"][1])
         if not t5:
             pd = lp + "model.decoder."
             pos_n = pd + "embed_positions.weight"
@@ -1158,7 +1273,12 @@ class Engine:
                              Ms, d)
         for i in range(lc.encoder_layers - 1, -1, -1):
             nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
-            dh = self.layer_bwd(dh, sv["enc_layers"][i], nm, pre_ln, act, rms=t5)
+            if "adapter" in sv["enc_layers"][i]:
+                dh = self.adapter_bwd(dh, sv["enc_layers"][i]["adapter"], i, Ms, d)
+            dh = self.layer_bwd(dh, sv["enc_layers"][i], nm, pre_ln, act, rms=t5,
+                                dbias=tb["encoder"][1] if "encoder" in tb else None)
+        if "encoder" in tb:
+            self._t5_bias_bwd(tb["encoder"], sv["t5_buckets"][0])
         if not t5:
             pe = lp + "model.encoder."
             pos_n = pe + "embed_positions.weight"
@@ -1202,14 +1322,10 @@ class Engine:
         out.update(loss=kld + ce + mse, ce=ce, kld=kld, mse=mse, dlogits=dlogits, extra_denc=dhs)
         return out
 
-    def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False,
-                lm_training=None):
-        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf);
-        prompt_ids [P] int64: token ids of a text prompt whose embeddings are prepended to every clip
-        (ref:speechmix/model.py:168-171, batch-expanded like ref:speechmix/hf_model.py:433-436)."""
-        self.st.refresh_shadow()
+    def speech_side_fwd(self, wave, training=False, prompt_ids=None, weighted_sum=False):
+        """Everything ahead of the LM: speech encoder -> (layer-weighted sum) -> length adapters -> enc_to_dec_proj ->
+        (text-prompt embeddings prepended).  -> (inputs_embeds [B*S, d_lm], S, state for speech_side_bwd, extras)."""
         B, N = wave.shape
-        Ld = dec_ids.shape[1]
         x, ssv = self.speech_fwd(wave, B, N, training)
         T, d = ssv["T"], self.ec.hidden_size
         ws = None
@@ -1234,39 +1350,12 @@ class Engine:
             # concatenation along time is pure data movement
             e = torch.cat((pe.view(1, P, dd).expand(B, P, dd), e.view(B, S, dd)), 1).contiguous().view(B * (P + S), dd)
             S = S + P
-        lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
-                            training=training if lm_training is None else lm_training)
-        self.saved = dict(speech=ssv, bridge=bsv, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], B=B, Ld=Ld,
-                          ws=ws, P=P, prompt_ids=prompt_ids)
-        return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=x, lm_enc_last=lo["lm_enc_last"],
-                    inputs_embeds=e, S=S, T=T, post_adapter=bsv["post_adapter"], hidden=ssv["hidden"], sw=ws,
-                    parts={k: lo[k] for k in ("ce", "kld", "mse") if k in lo})
+        state = dict(speech=ssv, bridge=bsv, B=B, ws=ws, P=P, prompt_ids=prompt_ids)
+        extras = dict(enc_last=x, T=T, post_adapter=bsv["post_adapter"], hidden=ssv["hidden"], sw=ws)
+        return e, S, state, extras
 
-    def backward(self, gscale=1.0, zero_grads=True):
-        ops.IN_BACKWARD = True           # kernel choice: see ops.PP_CONCURRENT_BACKWARD_OK
-        try:
-            self._backward(gscale, zero_grads)
-            if self.folds is not None:
-                self.folds.flush()       # anything queued after the last reported stage
-        finally:
-            ops.IN_BACKWARD = False
-            if self.folds is not None:
-                self.folds.items.clear()
-
-    def _backward(self, gscale, zero_grads):
-        sv = self.saved
-        if sv is None or sv["dlogits"] is None:
-            raise RuntimeError("backward() needs a forward() with labels")
-        if zero_grads:
-            self.st.grad.zero_()
-        extra = sv.get("extra_denc")
-        if extra is not None and gscale != 1.0:
-            extra = extra * gscale
-        if os.environ.get("SMX_LM_WGRAD_STREAM") != "0" and self.st.device.type == "cuda":
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream()
-            self._side_active = True
-        de = self.lm_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
+    def speech_side_bwd(self, de, sv):
+        """de: gradient wrt inputs_embeds [B*S, d_lm] (prompt rows included) -> all gradients ahead of the LM."""
         P = sv.get("P", 0)
         if P:
             lc, B = self.lc, sv["B"]
@@ -1294,4 +1383,51 @@ class Engine:
         self._stage("bridge")
         self.speech_bwd(dx, sv["speech"], ws=ws)
         self._stage("frontend")
+
+    def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False,
+                lm_training=None):
+        """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf);
+        prompt_ids [P] int64: token ids of a text prompt whose embeddings are prepended to every clip
+        (ref:speechmix/model.py:168-171, batch-expanded like ref:speechmix/hf_model.py:433-436)."""
+        self.st.refresh_shadow()
+        B = wave.shape[0]
+        Ld = dec_ids.shape[1]
+        e, S, state, ex = self.speech_side_fwd(wave, training, prompt_ids, weighted_sum)
+        lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
+                            training=training if lm_training is None else lm_training)
+        self.saved = dict(state, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], Ld=Ld)
+        return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=ex["enc_last"],
+                    lm_enc_last=lo["lm_enc_last"], inputs_embeds=e, S=S, T=ex["T"], post_adapter=ex["post_adapter"],
+                    hidden=ex["hidden"], sw=ex["sw"], parts={k: lo[k] for k in ("ce", "kld", "mse") if k in lo})
+
+    def backward(self, gscale=1.0, zero_grads=True):
+        ops.IN_BACKWARD = True           # kernel choice: see ops.PP_CONCURRENT_BACKWARD_OK
+        try:
+            self._backward(gscale, zero_grads)
+            if self.folds is not None:
+                self.folds.flush()       # anything queued after the last reported stage
+        finally:
+            ops.IN_BACKWARD = False
+            if self.folds is not None:
+                self.folds.items.clear()
+
+    def lm_side_bwd(self, dlogits, lsv, gscale, extra_denc=None):
+        """LM backward with the LM stage's weight gradients on the second compute stream (joined by the next _stage)."""
+        if os.environ.get("SMX_LM_WGRAD_STREAM") != "0" and self.st.device.type == "cuda":
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream()
+            self._side_active = True
+        return self.lm_bwd(dlogits, lsv, gscale, extra_denc=extra_denc)
+
+    def _backward(self, gscale, zero_grads):
+        sv = self.saved
+        if sv is None or sv["dlogits"] is None:
+            raise RuntimeError("backward() needs a forward() with labels")
+        if zero_grads:
+            self.st.grad.zero_()
+        extra = sv.get("extra_denc")
+        if extra is not None and gscale != 1.0:
+            extra = extra * gscale
+        de = self.lm_side_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
+        self.speech_side_bwd(de, sv)
         self.saved = None

@@ -20,7 +20,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
-from . import ops
+from . import checkpoint, ops
 from .configs import LMConfig, SpeechEncoderConfig, load_lm_config, load_speech_config
 from .engine import Engine
 from .params import (FlatStore, ParamTree, build_tree, init_lm, init_speech_encoder, spec_lm, spec_speech_encoder)
@@ -70,10 +70,14 @@ class Seq2SeqLMModule(ParamTree):
         owner = self._owner() if self._owner else None
         return owner.nlp_emb if owner is not None else None
 
-    def forward(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None, **_):
+    def forward(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None, attention_mask=None, **_):
+        """`decoder_model(inputs_embeds=..., decoder_input_ids=..., labels=...)` as the reference's cal_loss calls it
+        (ref:speechmix/model.py:132-137).  With autograd on and anything to differentiate (a trainable LM, or
+        inputs_embeds that require grad) the call is ONE autograd node over the engine's LM forward / backward, so a
+        subclass's own `cal_loss` can build its loss from `.logits` / `.loss`."""
         owner = self._owner()
-        return owner._lm_only(input_ids=input_ids, inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids,
-                              labels=labels)
+        return owner._lm_call(input_ids=input_ids, inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids,
+                              labels=labels, attention_mask=attention_mask)
 
 
 class TokenEmbedding(ParamTree):
@@ -113,6 +117,113 @@ class _StepFn(torch.autograd.Function):
             return (None, None, None, None, None, None) + grads
         model.store.publish_grads()
         return (None, None, None, None, None, torch.zeros((), device=gloss.device))
+
+
+class _SpeechFn(torch.autograd.Function):
+    """wave -> inputs_embeds [B, S, d_lm]: speech encoder, weighted sum, length adapters, projection (+ prompt)."""
+
+    @staticmethod
+    def forward(ctx, model, wave, training, prompt_ids, anchor):
+        eng = model.engine
+        model.store.refresh_shadow()
+        e, S, state, extras = eng.speech_side_fwd(wave, training, prompt_ids, model.weighted_sum)
+        ctx.model, ctx.state, ctx.token = model, state, model._step_token
+        model._last_speech = dict(extras, S=S, inputs_embeds=e)
+        return e.view(wave.shape[0], S, -1)
+
+    @staticmethod
+    def backward(ctx, ge):
+        model = ctx.model
+        eng = model.engine
+        model._begin_backward(ctx.token)
+        de = ge.reshape(-1, ge.shape[-1]).to(ops.torch_dtype(model.compute_dtype)).contiguous()
+        ops.IN_BACKWARD = True
+        try:
+            eng.speech_side_bwd(de, ctx.state)
+            if eng.folds is not None:
+                eng.folds.flush()
+        finally:
+            ops.IN_BACKWARD = False
+            if eng.folds is not None:
+                eng.folds.items.clear()
+        model.store.publish_grads()
+        return None, None, None, None, torch.zeros((), device=ge.device)
+
+
+class _LMFn(torch.autograd.Function):
+    """(inputs_embeds | input_ids, decoder_input_ids, labels) -> (logits [B, L, V] fp32, CE loss)."""
+
+    @staticmethod
+    def forward(ctx, model, emb, input_ids, dec, labels, training, anchor):
+        eng = model.engine
+        model.store.refresh_shadow()
+        B, Ld = dec.shape
+        if emb is not None:
+            S = emb.shape[1]
+            e2 = emb.to(ops.torch_dtype(model.compute_dtype)).contiguous().view(B * S, -1)
+            ids = None
+        else:
+            S = input_ids.shape[1]
+            e2, ids = None, input_ids.reshape(-1).contiguous()
+        logits, enc, lsv = eng.lm_fwd(e2, ids, dec.reshape(-1).contiguous(), B, S, Ld, training)
+        V, Vp = lsv["V"], lsv["Vp"]
+        M = B * Ld
+        loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        dlogits = None
+        if labels is not None:
+            am = torch.empty(M, dtype=torch.int64, device=logits.device)
+            dlogits = torch.empty(M, Vp, dtype=ops.torch_dtype(model.compute_dtype), device=logits.device)
+            ops.cross_entropy(logits, labels.reshape(-1).contiguous(), loss, am, dlogits, M, V, Vp, Vp, model.compute_dtype)
+        ctx.model, ctx.lsv, ctx.dlogits, ctx.labels, ctx.token = model, lsv, dlogits, labels, model._step_token
+        ctx.dims = (B, S, Ld, V, Vp, emb is not None)
+        ctx.set_materialize_grads(False)            # an unused output's gradient arrives as None, not as 200 MB of zeros
+        model._last_lm_enc = enc
+        return logits.view(B, Ld, Vp)[:, :, :V], loss.view(())
+
+    @staticmethod
+    def backward(ctx, glogits, gloss):
+        model = ctx.model
+        eng = model.engine
+        B, S, Ld, V, Vp, has_emb = ctx.dims
+        M = B * Ld
+        model._begin_backward(ctx.token)
+        cdt = ops.torch_dtype(model.compute_dtype)
+        g = float(gloss) if (gloss is not None and ctx.labels is not None) else 0.0
+        if glogits is None:
+            if ctx.dlogits is None or gloss is None:
+                return (None,) * 7
+            dl, gscale = ctx.dlogits, g
+        else:
+            # gradient arriving through `.logits` (a custom loss built on them): total = g * dCE/dlogits + user part.
+            # The CE kernel re-emits its gradient with the scale folded in; the user part is added by smx_add_f32_into.
+            dl = torch.zeros(M, Vp, dtype=cdt, device=glogits.device)
+            if ctx.dlogits is not None and g != 0.0:
+                tmp = torch.zeros(1, dtype=torch.float32, device=glogits.device)
+                am = torch.empty(M, dtype=torch.int64, device=glogits.device)
+                ops.cross_entropy(ctx.lsv["logits"], ctx.labels.reshape(-1).contiguous(), tmp, am, dl, M, V, Vp, Vp,
+                                  model.compute_dtype, gscale=g)
+            pad = torch.zeros(M, Vp, dtype=torch.float32, device=glogits.device)
+            pad[:, :V] = glogits.reshape(M, V)                      # (layout change only)
+            ops.add_f32_into(pad, dl, M * Vp, model.compute_dtype)
+            gscale = 1.0
+        ops.IN_BACKWARD = True
+        try:
+            de = eng.lm_side_bwd(dl, ctx.lsv, gscale)
+            eng._stage("lm")             # joins the weight-gradient stream, folds the stage's bias / LayerNorm partials
+        finally:
+            ops.IN_BACKWARD = False
+            if eng.folds is not None:
+                eng.folds.items.clear()
+        model.store.publish_grads()
+        zero = torch.zeros((), device=dl.device)
+        if not has_emb or not ctx.needs_input_grad[1]:
+            return (None,) * 6 + (zero,)
+        return None, de.view(B, S, -1), None, None, None, None, zero
+
+
+def _builtin(fn):
+    fn._smx_builtin = True
+    return fn
 
 
 class SpeechMixEED(nn.Module):
@@ -164,6 +275,9 @@ class SpeechMixEED(nn.Module):
         self.enc_to_dec_proj.add("weight", nn.Parameter(
             torch.empty(lm_cfg.d_model, d).uniform_(-k, k, generator=gen).to(self.device)))
         self.enc_to_dec_proj.add("bias", nn.Parameter(torch.empty(lm_cfg.d_model).uniform_(-k, k, generator=gen).to(self.device)))
+        # s3prl names carry no weights path: `speech_checkpoint=` points at the fairseq / HF weights to load by key name
+        enc_ckpt = kwargs.pop("speech_checkpoint", None) or enc_ckpt
+        lm_ckpt = kwargs.pop("nlp_checkpoint", None) or lm_ckpt
         if enc_ckpt:
             self._load_backbone(self.encoder_model, enc_ckpt)
         if lm_ckpt:
@@ -194,6 +308,10 @@ class SpeechMixEED(nn.Module):
         self.decoder_model._owner = weakref.ref(self)
         self.autograd_param_inputs = bool(kwargs.get("autograd_param_inputs", False))
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        self._step_token = 0          # one per forward(): the first autograd node of a step's backward zeroes the flat gradient
+        self._zeroed_token = -1
+        self._last_speech = None
+        self._last_lm_enc = None
         self._last = None
         self._pending_text_ids = None
         self._pending_prompt_ids = None
@@ -222,23 +340,10 @@ class SpeechMixEED(nn.Module):
         return None
 
     @staticmethod
-    def _load_backbone(tree, ckpt_dir):
-        path = os.path.join(ckpt_dir, "model.safetensors")
-        if not os.path.exists(path):
-            return
-        from safetensors.torch import load_file
-        sd = load_file(path)
-        own = dict(tree.state_dict())
-        fixed = {}
-        for k, v in sd.items():
-            for pre in ("wav2vec2.", "hubert."):
-                if k.startswith(pre):
-                    k = k[len(pre):]
-            k = k.replace("pos_conv_embed.conv.weight_g", "pos_conv_embed.conv.parametrizations.weight.original0")
-            k = k.replace("pos_conv_embed.conv.weight_v", "pos_conv_embed.conv.parametrizations.weight.original1")
-            if k in own and tuple(own[k].shape) == tuple(v.shape):
-                fixed[k] = v
-        tree.load_state_dict(fixed, strict=False)
+    def _load_backbone(tree, ckpt):
+        """HF directory (`model.safetensors` / `pytorch_model.bin`, sharded or not) or a weights file; speech encoders
+        also under fairseq / s3prl parameter names (speechmix_amd/checkpoint.py)."""
+        return checkpoint.load_backbone(tree, ckpt)
 
     def _build_engine(self):
         self.to(self.device)
@@ -253,8 +358,10 @@ class SpeechMixEED(nn.Module):
             self.store.rebind()
         return out
 
-    def load_state_dict(self, *a, **k):
-        out = super().load_state_dict(*a, **k)
+    def load_state_dict(self, state_dict, *a, **k):
+        """Accepts this package's names, the HF twin's (ref:speechmix/hf_model.py - identical) and state dicts saved from
+        ref:speechmix/model.py, whose speech encoder sits under `encoder_model.model.` with fairseq names (ref:eval.py:10)."""
+        out = super().load_state_dict(checkpoint.convert_speechmix_state_dict(state_dict), *a, **k)
         if self.store is not None:
             self.store.invalidate()
         return out
@@ -264,6 +371,14 @@ class SpeechMixEED(nn.Module):
             if p.requires_grad:
                 return p.grad is not None
         return False
+
+    def _begin_backward(self, token):
+        """First autograd node of a step's backward: zero the flat gradient unless `.grad`s are live (accumulation)."""
+        if self._zeroed_token == token:
+            return
+        self._zeroed_token = token
+        if not self._grads_live():
+            self.store.grad.zero_()
 
     # ------------------------------------------------------------------ reference hooks
     def custom_modules(self, **kwargs):
@@ -317,6 +432,31 @@ class SpeechMixEED(nn.Module):
             out["loss"] = loss.view(())
         return out
 
+    def _lm_call(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None, attention_mask=None):
+        """`decoder_model(...)`: autograd node when something can be differentiated, plain evaluation otherwise."""
+        self._need_engine()
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask: the reference never passes one to the LM (ref:speechmix/model.py:172-173)")
+        lc = self.decoder_model.config
+        lm_trainable = any(p.requires_grad for p in self.decoder_model.parameters())
+        emb_grad = inputs_embeds is not None and inputs_embeds.requires_grad
+        if not (torch.is_grad_enabled() and (lm_trainable or emb_grad)):
+            return self._lm_only(input_ids=input_ids, inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids,
+                                 labels=labels)
+        if decoder_input_ids is None and labels is not None:
+            decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
+        dec = decoder_input_ids.to(self.device).contiguous()
+        lab = labels.to(self.device).contiguous() if labels is not None else None
+        ids = input_ids.to(self.device).contiguous() if input_ids is not None else None
+        emb = inputs_embeds.to(self.device) if inputs_embeds is not None else None
+        self.engine._check_ids(lab, lc.vocab_size, "labels", allow_ignore=True)
+        logits, loss = _LMFn.apply(self, emb, ids, dec, lab, self.training and self.decoder_model.training, self._anchor)
+        B = dec.shape[0]
+        out = _Out(logits=logits, encoder_last_hidden_state=self._last_lm_enc.view(B, -1, lc.d_model).float())
+        if lab is not None:
+            out["loss"] = loss
+        return out
+
     # ------------------------------------------------------------------ greedy decoding (SURVEY.md §8f rank 1)
     def _greedy(self, enc, B, S, max_length):
         lc = self.decoder_model.config
@@ -364,9 +504,15 @@ class SpeechMixEED(nn.Module):
             max_length = max(int(getattr(self.decoder_model.config, "max_length", 20) or 20), S)
         return self._greedy(enc, B, S, max_length)
 
+    @_builtin
     def cal_loss(self, inputs_embeds=None, attention_mask=None, decoder_input_ids=None, labels=None):
-        """ref:speechmix/model.py:132-137 - LM on `inputs_embeds` (no speech side, no autograd)."""
-        return self._lm_only(inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids, labels=labels)
+        """ref:speechmix/model.py:132-137 - the overridable hook `forward` dispatches through: the LM on `inputs_embeds`.
+        A subclass that overrides it gets `inputs_embeds` as a differentiable tensor and `self.decoder_model(...)` as a
+        differentiable call; this built-in one is recognised by `forward`, which then runs the fused single-node step
+        (same arithmetic, no [B, L, V] logits handed to autograd)."""
+        if inputs_embeds is not None:
+            return self.decoder_model(inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                                      decoder_input_ids=decoder_input_ids, labels=labels)
 
     def _lm_training(self):
         """Dropout mode of the LM: module state, like nn.Module.training drives HF's dropout calls; SpeechMixSelf
@@ -376,11 +522,24 @@ class SpeechMixEED(nn.Module):
         return self.training and self.decoder_model.training
 
     # ------------------------------------------------------------------ forward (ref:speechmix/model.py:139-177)
+    def _argmax_ids(self, logits):
+        """argmax(logits, -1) through the fused CE / arg-max kernel (ref:speechmix/model.py:174)."""
+        B, Ld, V = logits.shape
+        lg = logits.detach()
+        if lg.dtype != torch.float32 or lg.stride(2) != 1 or lg.stride(0) != Ld * lg.stride(1):
+            lg = lg.float().contiguous()
+        am = torch.empty(B * Ld, dtype=torch.int64, device=lg.device)
+        ld = lg.stride(1)
+        ops.cross_entropy(lg, None, None, am, None, B * Ld, V, ld, ld, self.compute_dtype)
+        return am.view(B, Ld)
+
     def forward(self, input_values, input_text_prompt=None, decoder_input_ids=None, labels=None,
                 return_model_detail=False, text_input_ids=None):
         self._need_engine()
         lc = self.decoder_model.config
         wave = self._prep_wave(input_values)
+        if labels is not None:
+            self.engine._check_ids(labels, lc.vocab_size, "labels", allow_ignore=True)
         if decoder_input_ids is None and labels is None:
             decoder_input_ids = handle_decoder_input_none(lc, len(wave), device=self.device)
         elif decoder_input_ids is None and labels is not None:
@@ -399,6 +558,37 @@ class SpeechMixEED(nn.Module):
         return_dict = {}
         want_grad = torch.is_grad_enabled() and lab is not None and len(self.list_grad) > 0
         text = text_input_ids.to(self.device).contiguous() if (text_input_ids is not None and self._uses_text_ids) else None
+        self._step_token += 1
+        B, Ld = dec.shape
+        d = self.encoder_model.config.hidden_size
+        # The reference's forward ends in `self.cal_loss(inputs_embeds=..., decoder_input_ids=..., labels=...)`
+        # (ref:speechmix/model.py:172-173).  The built-in hooks (EED: LM + CE; Self: CE + KLD + MSE) are what the fused
+        # single-node step computes, so they are taken on the fast path; an overridden hook is CALLED, with a differentiable
+        # `inputs_embeds` from the speech-side autograd node and a differentiable `self.decoder_model(...)`.
+        if not getattr(type(self).cal_loss, "_smx_builtin", False):
+            e = _SpeechFn.apply(self, wave, training, prompt_ids, self._anchor)
+            if not torch.is_grad_enabled():
+                e = e.detach()
+            kw = dict(inputs_embeds=e, decoder_input_ids=dec, labels=lab)
+            if self._uses_text_ids:
+                kw["text_input_ids"] = text
+            outputs = self.cal_loss(**kw)
+            sp = self._last_speech
+            T, S = sp["T"], sp["S"]
+            if return_model_detail:
+                dd = lc.d_model
+                return_dict["shape_before_length_adapter"] = torch.Size((B, T, d))
+                return_dict["shape_before_enc_dec_projector"] = torch.Size((B, S, d))
+                return_dict["shape_after_enc_dec_projector"] = torch.Size((B, S, dd))
+                return_dict["raw_logits"] = outputs["logits"]
+                return_dict["encoder_last_hidden_state"] = sp["enc_last"].view(B, T, d).float()
+                return_dict["inputs_embeds"] = e.detach().float()
+                if sp.get("sw") is not None:
+                    return_dict["weighted_sum"] = sp["sw"]
+            return_dict["logits"] = self._argmax_ids(outputs["logits"])
+            if "loss" in outputs and outputs["loss"] is not None:
+                return_dict["loss"] = outputs["loss"]
+            return return_dict
         if want_grad:
             params = tuple(self.store.params.values()) if self.autograd_param_inputs else ()
             self._pending_text_ids, self._pending_prompt_ids = text, prompt_ids
@@ -409,9 +599,7 @@ class SpeechMixEED(nn.Module):
                                       weighted_sum=self.weighted_sum, lm_training=self._lm_training())
             loss = out["loss"].view(()) if out["loss"] is not None else None
             self.engine.saved = None
-        B, Ld = dec.shape
         if return_model_detail:
-            d = self.encoder_model.config.hidden_size
             T, S, dd = out["T"], out["S"], lc.d_model
             return_dict["shape_before_length_adapter"] = torch.Size((B, T, d))
             return_dict["shape_before_enc_dec_projector"] = torch.Size((B, S, d))
@@ -447,6 +635,40 @@ class SpeechMixFixed(SpeechMixEED):
                 param.requires_grad = False
 
 
+class SpeechMixAdapter(SpeechMixEED):
+    """ref:speechmix/model.py:196-222: the LM's encoder / decoder layer stacks are frozen and a bottleneck adapter
+    `Sequential(LayerNorm(d), Linear(d, d/2), ReLU(), Linear(d/2, d))` replaces every layer's hidden-state output
+    (forward hook, no residual).  State-dict names as in the reference: `adapters.{i}.{0,1,3}.{weight,bias}`,
+    i = stack * layers + layer.  The reference registers its hooks with lambdas that capture the loop variables late, so at
+    this commit every hook runs the LAST adapter (and with transformers 5.x, whose layers return a tensor, the hook's
+    `(adapter(o[0]), o[1:])` breaks the forward outright - probed in the build container); what is built here is the evident
+    intent, one adapter per layer."""
+
+    def custom_modules(self, **kwargs):
+        self.encoder_model.eval()
+        self.decoder_model.eval()
+        lc = self.decoder_model.config
+        t5 = lc.model_type == "t5"
+        stacks = ("encoder.block.", "decoder.block.") if t5 else ("model.encoder.layers.", "model.decoder.layers.")
+        for name, param in self.decoder_model.named_parameters():
+            if name.startswith(stacks) and param.requires_grad:
+                param.requires_grad = False
+        d = lc.d_model
+        bottleneck = int(d / 2)
+        gen = torch.Generator().manual_seed(int(kwargs.get("adapter_seed", 0)))
+        self.adapters = nn.ModuleList()
+        for _ in range(lc.encoder_layers + lc.decoder_layers):
+            m = ParamTree()
+            m.add("0.weight", nn.Parameter(torch.ones(d)))
+            m.add("0.bias", nn.Parameter(torch.zeros(d)))
+            for idx, (fo, fi) in (("1", (bottleneck, d)), ("3", (d, bottleneck))):      # nn.Linear's default init
+                k = math.sqrt(1.0 / fi)
+                m.add(idx + ".weight", nn.Parameter(torch.empty(fo, fi).uniform_(-k, k, generator=gen)))
+                m.add(idx + ".bias", nn.Parameter(torch.empty(fo).uniform_(-k, k, generator=gen)))
+            self.adapters.append(m)
+        self.adapters.to(self.device)
+
+
 class SpeechMixSelf(SpeechMixEED):
     """ref:speechmix/model.py:225-266: frozen LM; loss = KLD(speech logits || text logits) + CE + MSE(attention-pooled
     speech hidden, text hidden).  Unlike the reference at this commit, `forward` accepts
@@ -460,6 +682,7 @@ class SpeechMixSelf(SpeechMixEED):
             if param.requires_grad:
                 param.requires_grad = False
 
+    @_builtin
     def cal_loss(self, inputs_embeds=None, text_input_ids=None, attention_mask=None, decoder_input_ids=None, labels=None):
         """Direct (no-autograd) evaluation of the three losses on given `inputs_embeds`, like calling the
         reference's cal_loss: returns an output with .logits [B,L,V], .loss and the separate terms."""

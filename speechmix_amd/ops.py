@@ -327,6 +327,12 @@ def attention_bwd(desc, lse, delta, dtype, dbias=None):
     L.check(L.lib().smx_attention_bwd(C.byref(desc.p), dtype, _stream()), "smx_attention_bwd")
 
 
+def attn_bias_scatter(dbias, bucket, dtable, H, Tq, Tk, nbuckets):
+    """dtable[bucket[q, k], h] += dbias[h, q, k] (T5 relative-position bias table gradient)."""
+    L.check(L.lib().smx_attn_bias_scatter(C.c_void_p(_ptr(dbias)), C.c_void_p(_ptr(bucket)), C.c_void_p(_ptr(dtable)), H, Tq, Tk,
+                                          nbuckets, _stream()), "smx_attn_bias_scatter")
+
+
 def conv0_workspace_floats(B, Cc, k):
     fn = L.lib().smx_conv0_workspace_floats
     fn.restype = C.c_longlong
@@ -542,6 +548,12 @@ class AdafactorPlan:
         self.beta2t = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.steps = np.zeros(self.n, dtype=np.int64)          # per-tensor step counts (HF keeps state["step"] per tensor)
         self._np = np
+        # beta2t travels through a small ring of PINNED host buffers: an asynchronous copy from pageable memory is either a
+        # hidden host-synchronous staged copy or a read of a freed buffer; a ring slot is reused only after its copy's event
+        self._b2_host = [torch.empty(self.n, dtype=torch.float32).pin_memory() if dev.type == "cuda" else
+                         torch.empty(self.n, dtype=torch.float32) for _ in range(4)]
+        self._b2_ev = [None] * 4
+        self._b2_i = 0
 
     def step(self, p, g, shadow, gnorm_sq, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
              max_grad_norm=0.0):
@@ -550,7 +562,15 @@ class AdafactorPlan:
         act = np.ones(self.n, dtype=bool) if active is None else np.asarray(active, dtype=bool)
         self.steps[act] += 1
         b2 = np.where(act, 1.0 - np.power(np.maximum(self.steps, 1).astype(np.float64), decay_rate), -1.0).astype(np.float32)
-        self.beta2t.copy_(torch.from_numpy(b2), non_blocking=True)
+        i = self._b2_i
+        self._b2_i = (i + 1) % len(self._b2_host)
+        if self._b2_ev[i] is not None:
+            self._b2_ev[i].synchronize()                 # (4 steps old: long complete)
+        self._b2_host[i].numpy()[:] = b2
+        self.beta2t.copy_(self._b2_host[i], non_blocking=True)
+        if self.beta2t.is_cuda:
+            self._b2_ev[i] = torch.cuda.Event()
+            self._b2_ev[i].record()
         o = L.AfParams()
         o.p, o.g, o.shadow = _ptr(p), _ptr(g), _ptr(shadow)
         o.tensors, o.tiles, o.segs = _ptr(self.tensors), _ptr(self.tiles), _ptr(self.segs)

@@ -349,6 +349,9 @@ class FlatStore:
     def requires_grad(self, name):
         return self.params[name].requires_grad
 
+    def has_prefix(self, prefix):
+        return any(n.startswith(prefix) for n in self.offsets)
+
     def refresh_shadow(self, force=False):
         """bf16 compute copies follow the fp32 masters (no-op when nothing changed / fp32 path)."""
         if self.shadow is self.master:

@@ -17,9 +17,11 @@ from . import ops
 from .dist import GradReducer, stage_ranges
 
 
-def trainable_ranges(store) -> List[Tuple[int, int]]:
-    """Maximal runs of consecutive trainable parameters in the flat buffer (alignment gaps are merged)."""
-    items = sorted((o, o + n, store.requires_grad(name)) for name, (o, n, _) in store.offsets.items())
+def trainable_ranges(store, skip_layers=(), layer_of=None) -> List[Tuple[int, int]]:
+    """Maximal runs of consecutive parameters that are updated this step in the flat buffer (alignment gaps are merged):
+    trainable, and not belonging to a speech-encoder layer in `skip_layers` (LayerDrop left it without a gradient)."""
+    items = sorted((o, o + n, store.requires_grad(name) and not (layer_of and layer_of.get(name, -1) in skip_layers))
+                   for name, (o, n, _) in store.offsets.items())
     out: List[List[int]] = []
     prev_trainable = False
     for a, b, tr in items:
@@ -32,12 +34,26 @@ def trainable_ranges(store) -> List[Tuple[int, int]]:
     return [(a, b) for a, b in out]
 
 
+def linear_schedule_with_warmup(lr, warmup_steps, total_steps):
+    """HF Trainer's default schedule, which the reference trains with (ref:train.py:305-306: learning_rate 5e-4,
+    warmup_steps 500; TF:optimization.py get_linear_schedule_with_warmup): step (1-based) -> learning rate."""
+    def f(step):
+        s = step - 1
+        if s < warmup_steps:
+            return lr * s / max(1, warmup_steps)
+        return lr * max(0.0, (total_steps - s) / max(1, total_steps - warmup_steps))
+    return f
+
+
 class StepRunner:
     def __init__(self, model, lr=4e-5, optimizer="adamw", betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_grad_norm=1.0, momentum=0.0, force_comm=False, grad_accum=1):
-        """grad_accum: micro-batches per optimizer step (the reference trains with HF Trainer's
+                 max_grad_norm=1.0, momentum=0.0, force_comm=False, grad_accum=1, sync_params=True):
+        """lr: a float, or a callable step -> lr (`linear_schedule_with_warmup`).
+        grad_accum: micro-batches per optimizer step (the reference trains with HF Trainer's
         gradient_accumulation_steps, ref:train.py:159, 295: every micro-batch's loss is divided by it, gradients add up, and
-        the all-reduce / clip / optimizer update run on the last one)."""
+        the all-reduce / clip / optimizer update run on the last one).
+        sync_params: with more than one rank, broadcast rank 0's parameters at construction (DDP does the same), so that
+        ranks cannot start from different weights."""
         model._need_engine()
         self.grad_accum = max(1, int(grad_accum))
         self._micro = 0
@@ -56,27 +72,44 @@ class StepRunner:
         self.v = torch.zeros(n, dtype=torch.float32, device=dev) if optimizer == "adamw" else None
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
-        self.ranges = trainable_ranges(self.store)
+        ep = self.engine.ep
+        pre = ep + "encoder.layers."
+        # speech-encoder layer index of every parameter (LayerDrop bookkeeping), -1 elsewhere
+        self.layer_of = {nm: (int(nm[len(pre):].split(".", 1)[0]) if nm.startswith(pre) else -1) for nm in self.store.offsets}
         self.af = None
         if optimizer == "adafactor":
             # the reference's optimizer (ref:train.py:298 -> HF Trainer: Adafactor(lr, scale_parameter=False,
-            # relative_step=False)); one fused multi-tensor step over the flat buffer (csrc/adafactor.hip)
-            self.af_names = [nm for nm, _ in sorted(self.store.offsets.items(), key=lambda kv: kv[1][0])
-                             if self.store.requires_grad(nm)]
+            # relative_step=False)); one fused multi-tensor step over the flat buffer (csrc/adafactor.hip).  The plan covers
+            # EVERY parameter; the per-step `active` mask carries requires_grad (FreezingCallback toggles it while training,
+            # ref:speechmix/module/utility.py:14-29) and LayerDrop, so optimizer state survives a freeze / unfreeze like HF's.
+            self.af_names = [nm for nm, _ in sorted(self.store.offsets.items(), key=lambda kv: kv[1][0])]
             self.af = ops.AdafactorPlan([(self.store.offsets[nm][0], self.store.offsets[nm][2]) for nm in self.af_names], dev)
-            ep = self.engine.ep
-            self._af_layer = [-1] * len(self.af_names)             # encoder layer index of each tensor (LayerDrop bookkeeping)
-            for i, nm in enumerate(self.af_names):
-                pre = ep + "encoder.layers."
-                if nm.startswith(pre):
-                    self._af_layer[i] = int(nm[len(pre):].split(".", 1)[0])
-        self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, model.num_speech_encoder_layers),
-                                   force_comm=force_comm)
-        self.engine.stage_cb = self.reducer.stage_done
+            self._af_layer = [self.layer_of[nm] for nm in self.af_names]
+        self._flags = None
+        self._force_comm = force_comm
+        self._refresh_trainable()
         if self.world > 1 or force_comm:
             ops.PP_CONCURRENT_BACKWARD_OK = False   # RCCL runs beside backward: one-workgroup-per-CU kernels would be displaced
+        if self.world > 1 and sync_params:
+            dist.broadcast(self.store.master, src=0)
         self.store.external_updates = False          # this runner keeps the bf16 compute copies fresh itself
         self.store.refresh_shadow(force=True)
+
+    def _refresh_trainable(self):
+        """(Re)derive everything that depends on the requires_grad flags - update ranges, reduction buckets - when they
+        change (the reference's FreezingCallback flips them at a step boundary on every rank alike)."""
+        flags = tuple(self.store.requires_grad(nm) for nm in self.store.offsets)
+        if flags == self._flags:
+            return
+        self._flags = flags
+        self.ranges = trainable_ranges(self.store)
+        self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, self.model.num_speech_encoder_layers,
+                                                                 trainable=self.store.requires_grad),
+                                   force_comm=self._force_comm)
+        self.engine.stage_cb = self.reducer.stage_done
+
+    def current_lr(self):
+        return float(self.lr(self.t)) if callable(self.lr) else float(self.lr)
 
     def step(self, input_values, labels, decoder_input_ids=None, text_input_ids=None):
         """One optimizer step on this rank's shard.  Returns the (device) loss tensor of this rank."""
@@ -91,6 +124,7 @@ class StepRunner:
         last = self._micro == ga - 1
         self._micro = 0 if last else self._micro + 1
         if first:
+            self._refresh_trainable()
             self.reducer.begin_step()
         text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
         out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(),
@@ -108,24 +142,26 @@ class StepRunner:
             return out["loss"]
         self.reducer.finish()
         self.t += 1
+        lr = self.current_lr()
         inv_world = 1.0 / self.world
         clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
         if clip > 0:
             ops.sumsq(st.grad, st.total, self.gnorm_sq)
         sh = None if st.shadow is st.master else st.shadow
+        # torch / HF optimizers skip parameters whose .grad is None: a LayerDrop-dropped layer's (on one rank; across ranks the
+        # all-reduce gives every tensor a gradient) and frozen ones
+        dropped = self._dropped_all if self.world == 1 else set()
         if self.af is not None:
-            active = None
-            if self.world == 1 and self._dropped_all:     # HF skips parameters without a gradient (a dropped layer's);
-                dropped = self._dropped_all               # across ranks the all-reduce gives every tensor a gradient
-                active = [l not in dropped for l in self._af_layer]
-            self.af.step(st.master, st.grad, sh, self.gnorm_sq if clip > 0 else None, self.lr, active=active,
+            active = [f and (l not in dropped) for f, l in zip((st.requires_grad(nm) for nm in self.af_names), self._af_layer)]
+            self.af.step(st.master, st.grad, sh, self.gnorm_sq if clip > 0 else None, lr, active=active,
                          grad_scale=inv_world, max_grad_norm=clip)
             st.mark_shadow_fresh()
             return out["loss"]
-        for a, b in self.ranges:
+        ranges = self.ranges if not dropped else trainable_ranges(st, dropped, self.layer_of)
+        for a, b in ranges:
             ops.optimizer_step(st.master[a:b], st.grad[a:b], self.m[a:b] if self.m is not None else None,
                                self.v[a:b] if self.v is not None else None, sh[a:b] if sh is not None else None,
-                               self.gnorm_sq if clip > 0 else None, b - a, self.lr, kind=self.kind,
+                               self.gnorm_sq if clip > 0 else None, b - a, lr, kind=self.kind,
                                beta1=self.betas[0] if self.kind == "adamw" else self.momentum, beta2=self.betas[1],
                                eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=inv_world, max_grad_norm=clip)
         st.mark_shadow_fresh()

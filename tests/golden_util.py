@@ -9,8 +9,13 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def manifest():
-    with open(os.path.join(GOLDEN, "manifest.json")) as f:
-        return json.load(f)
+    out = {}
+    for name in ("manifest.json", "manifest_r2.json"):      # round-2 fixtures (make_golden_r2.py) live beside round 1's
+        path = os.path.join(GOLDEN, name)
+        if os.path.exists(path):
+            with open(path) as f:
+                out.update(json.load(f))
+    return out
 
 
 def load_case(name):

@@ -68,3 +68,74 @@ def test_bucketed_allreduce_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == (0, True, (0, 32)) and res[1] == (1, True, (32, 64))
+
+
+def _worker_real_layout(rank, world, port, q):
+    """GradReducer over the REAL config-2 FlatStore layout (wav2vec2-base + bart-base: 235.6 M parameters, q|k|v adjacency,
+    alignment padding, tied embedding stored once) with per-rank-different LayerDrop sets and grad_accum = 2: micro-batch
+    gradients add up locally, only the last micro-batch reports stages (StepRunner.step), dropped layers contribute zeros."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import contextlib, io
+        from speechmix_amd.dist import GradReducer, stage_ranges
+        from speechmix_amd.model import SpeechMixFixed
+        from speechmix_amd.params import FlatStore
+        torch.set_num_threads(2)
+        with contextlib.redirect_stdout(io.StringIO()):
+            # SpeechMixFixed(fixed_nlp) = frozen LM: its 139 M parameters must not be reduced at all
+            model = SpeechMixFixed("facebook/wav2vec2-base", "facebook/bart-base", down_scale=2, fixed_nlp=True)
+        store = FlatStore(model, "cpu", torch.float32)
+        L = model.num_speech_encoder_layers
+        stages = stage_ranges(store.offsets, L, trainable=store.requires_grad)
+        red = GradReducer(store.grad, stages)
+        covered = sum(b - a for _, rs in stages for a, b in rs)
+        lm_elems = sum(n for nm, (o, n, _) in store.offsets.items() if nm.startswith("decoder_model."))
+        trainable_elems = sum(n for nm, (o, n, _) in store.offsets.items() if store.requires_grad(nm))
+        assert covered >= trainable_elems and covered < trainable_elems + 64 * len(store.offsets), (covered, trainable_elems)
+        assert covered < store.total - lm_elems + 64 * len(store.offsets)            # the frozen LM is outside every bucket
+        pre = "encoder_model.encoder.layers."
+        layer_of = {nm: int(nm[len(pre):].split(".")[0]) for nm in store.offsets if nm.startswith(pre)}
+        drops = {0: [{1, 5}, {5, 7}], 1: [{2}, {5, 11}]}          # [rank][micro-batch]: LayerDrop decisions differ per rank
+        order = ["lm", "bridge"] + [f"enc_layer{i}" for i in range(L - 1, -1, -1)] + ["frontend"]
+        red.begin_step()
+        store.grad.zero_()
+        for micro in range(2):
+            for nm, (o, n, _) in store.offsets.items():
+                if not store.requires_grad(nm) or layer_of.get(nm, -1) in drops[rank][micro]:
+                    continue
+                store.grad[o:o + n] += 0.5 * (rank + 1) * (micro + 1)           # (gscale = 1 / grad_accum folded in)
+            if micro == 1:                                                       # stages are reported on the last micro-batch only
+                for s in order[:-1]:
+                    red.stage_done(s)
+        red.finish()
+        ok, checked = True, 0
+        for nm, (o, n, _) in store.offsets.items():
+            if not store.requires_grad(nm):
+                ok &= bool((store.grad[o:o + n] == 0).all())
+                continue
+            want = 0.0
+            for r in range(world):
+                for micro in range(2):
+                    if layer_of.get(nm, -1) not in drops[r][micro]:
+                        want += 0.5 * (r + 1) * (micro + 1)
+            ok &= bool(torch.allclose(store.grad[o:o + n], torch.full((n,), want)))
+            checked += 1
+        q.put((rank, bool(ok), checked > 150, covered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_on_real_config2_layout_with_layerdrop_and_grad_accum():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real_layout, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1] and res[0][2] and res[0][3] == res[1][3], res

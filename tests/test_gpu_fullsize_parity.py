@@ -1,0 +1,109 @@
+"""Parity at the REAL dimensions: wav2vec2-base + bart-base (d 768, 12 heads, FFN 3072, V 50 265,
+down_scale 2), random-init seed 0, 2 clips x 3 s so that the CPU oracle's forward + backward takes seconds - the HIP
+fp32 AND bf16 paths against `oracle.speechmix_eed_forward`, forward and backward; and both bf16 GEMM kernels against an
+fp32 reference at the model's GEMM shapes (the 15 968-row encoder GEMMs, their weight gradients, a 512 k-row conv view).
+
+Bounds.  fp32: logits <= 1e-3 (north_star), arg-max equal wherever the oracle's top-2 margin exceeds twice the error,
+gradients <= 2e-3 of each tensor's max.  bf16 (the benched dtype: bf16 storage of every activation and weight, fp32
+accumulation): 3x the errors measured on the MI355X by tools/gpu_fullsize_parity.py (recorded next to each bound)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_REF = {}
+
+
+def _run(dtype):
+    from tools.gpu_fullsize_parity import run
+    res, ref = run(dtype, ref=_REF.get("ref"))
+    _REF["ref"] = ref
+    print(f"[full-size {dtype}] " + ", ".join(f"{k} {v:.3e}" for k, v in res.items() if isinstance(v, float)))
+    return res
+
+
+def test_fullsize_fp32_matches_oracle():
+    r = _run("fp32")
+    assert r["logits"] <= 1e-3 and r["loss"] <= 1e-4
+    assert r["encoder_last_hidden_state"] <= 1e-3 and r["lm_encoder_last_hidden"] <= 1e-3 and r["inputs_embeds"] <= 1e-3
+    assert r["argmax_checked"] > 0 and r["argmax_equal"]
+    assert r["grad_worst"] <= 2e-3, (r["grad_worst_name"], r["grad_worst"])
+
+
+# measured on the MI355X (gpurun_out/r2/parity0.log): see BF16_BOUNDS below = 3 x measured, rounded up
+BF16_BOUNDS = dict(logits=1.5e-1, loss=5e-2, encoder_last_hidden_state=1.5e-1, lm_encoder_last_hidden=1.5e-1, inputs_embeds=1.5e-1,
+                   grad_worst=2.5e-1)
+
+
+def test_fullsize_bf16_matches_oracle_within_measured_bounds():
+    r = _run("bf16")
+    for k, b in BF16_BOUNDS.items():
+        assert r[k] <= b, (k, r[k], b, r.get("grad_worst_name"))
+    assert r["argmax_checked"] > 0 and r["argmax_equal"]
+
+
+@pytest.mark.parametrize("M,N,K", [(15968, 768, 768), (15968, 2304, 768), (15968, 3072, 768), (15968, 768, 3072)])
+def test_bf16_gemm_kernels_vs_fp32_reference_at_model_shapes(M, N, K):
+    """Both production kernels (128x128 LDS-DMA and 256x256 ping-pong), all three operand layouts the model uses
+    (forward KC.KC, data gradient KC.RC, weight gradient RC.RC over 15 968 rows with its K split), against an fp32 matmul
+    of the same bf16-rounded operands.  Bound: bf16 output rounding (2^-8 relative) + fp32 accumulation-order noise."""
+    from speechmix_amd import ops
+    from speechmix_amd.ops import view
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = A.float() @ W.float().t() + bias
+    sc = ref.abs().max().item()
+    Wt = W.t().contiguous()
+    dY = torch.randn(M, N, generator=g).to(dev).bfloat16()
+    ref_w = dY.float().t() @ A.float()                      # [N, K] weight gradient, reduction over M = 15 968 rows
+    scw = ref_w.abs().max().item()
+    for mode in (1, 8):
+        Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, Y, M, N, K, ops.BF16, bias=bias, tr_mode=mode)
+        e = (Y.float() - ref).abs().max().item()
+        print(f"fwd   {M}x{N}x{K} mode {mode}: err {e:.3e} / {sc:.3e}")
+        assert e <= 2 ** -7 * sc
+        Y.zero_()
+        ops.gemm(A, Wt, Y, M, N, K, ops.BF16, b_rc=True, bv=view(N), bias=bias, tr_mode=mode)     # W read rows-contiguous
+        e = (Y.float() - ref).abs().max().item()
+        print(f"dgrad {M}x{N}x{K} mode {mode}: err {e:.3e} / {sc:.3e}")
+        assert e <= 2 ** -7 * sc
+        kst = (M + 63) // 64
+        for split in (1, 7):
+            per = (kst + split - 1) // split
+            sp = (kst + per - 1) // per
+            S = torch.zeros(sp, N, K, dtype=torch.float32, device=dev)
+            ops.gemm(dY, A, S, N, K, M, ops.BF16, a_rc=True, b_rc=True, av=view(N), bv=view(K), out_f32=True, split_k=sp,
+                     split_stride=N * K if sp > 1 else 0, tr_mode=mode)
+            e = (S.sum(0) - ref_w).abs().max().item()
+            print(f"wgrad {N}x{K}x{M} split {sp} mode {mode}: err {e:.3e} / {scw:.3e}")
+            assert e <= 2e-5 * scw + 1e-3                   # fp32 out: accumulation-order noise only
+
+
+def test_bf16_conv_view_gemm_vs_fp32_reference_at_512k_rows():
+    """Conv layer 1 of the feature extractor as the engine runs it: A = overlapping row view of the channels-last
+    activation [B * 31 999, 512] (row r -> window of 3 x 512 starting at frame 2 r of its clip), 511 968 rows in total."""
+    from speechmix_amd import ops
+    from speechmix_amd.ops import view
+    dev = torch.device("cuda:0")
+    B, Tin, Cin, Co, k, s = 32, 31999, 512, 512, 3, 2
+    To = (Tin - k) // s + 1
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B * Tin, Cin, generator=g) * 0.5).to(dev).bfloat16()
+    w = (torch.randn(Co, k * Cin, generator=g) * 0.03).to(dev).bfloat16()
+    av = view(s * Cin, To, Tin * Cin)
+    for mode in (1, 8):
+        y = torch.zeros(B * To, Co, dtype=torch.bfloat16, device=dev)
+        ops.gemm(x, w, y, B * To, Co, k * Cin, ops.BF16, av=av, tr_mode=mode)
+        worst = 0.0
+        for b in (0, 13, 31):                               # three clips checked in full against fp32 unfold + matmul
+            xb = x[b * Tin:(b + 1) * Tin].float()
+            cols = torch.cat([xb[j:j + s * (To - 1) + 1:s] for j in range(k)], 1)      # [To, k * Cin]
+            ref = cols @ w.float().t()
+            e = (y[b * To:(b + 1) * To].float() - ref).abs().max().item() / ref.abs().max().item()
+            worst = max(worst, e)
+        print(f"conv view 511968x512x1536 mode {mode}: rel err {worst:.3e}")
+        assert worst <= 2 ** -7
