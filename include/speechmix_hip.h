@@ -71,7 +71,13 @@ typedef struct SmxAttnParams {
     const void *Q, *K, *V; void* O; float* lse; const float* bias; const void* dO; void *dQ, *dK, *dV; float *delta, *dbias;
     long long q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, do_bs, do_ld;
     int B, H, Tq, Tk, D, causal; float scale; float drop_p; unsigned drop_seed;
+    unsigned *mask_q, *mask_k;   /* dropout keep bits, both orientations (bf16 / head_dim 64 path; smx_attn_dropout_mask) */
 } SmxAttnParams;
+/* Attention-probability dropout on the MFMA path (TF:models/wav2vec2/modeling_wav2vec2.py:533-536 nn.functional.dropout on the
+ * probabilities): smx_attn_mask_words gives the sizes (32-bit words, 0/0 when no mask is needed), smx_attn_dropout_mask
+ * fills both bit matrices for (drop_p, drop_seed) - the same keep decisions as every other dropout site of the library. */
+int smx_attn_mask_words(const SmxAttnParams* p, int dtype, long long* nq, long long* nk);
+int smx_attn_dropout_mask(const SmxAttnParams* p, hipStream_t stream);
 int smx_attention_fwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
 int smx_attention_bwd(const SmxAttnParams* p, int dtype, hipStream_t stream);
 /* T5 relative-position bias gradient: smx_attention_bwd with p->dbias set accumulates dbias[H,Tq,Tk] += sum_b dS; this

@@ -29,6 +29,9 @@ struct SmxAttnParams {
     float scale;
     float drop_p;         // dropout on the attention probabilities (0: off); mask index = ((b*H+h)*Tq+q)*Tkp+key, Tkp = Tk rounded up to a multiple of 4
     unsigned drop_seed;
+    // MFMA path with dropout: the keep mask as bit matrices, written by smx_attn_dropout_mask (attention_v2.h):
+    unsigned* mask_q;     // [B*H*Tq][2*ceil(Tk/64)] words, bit j of word w = key 32 w + j   (forward, dQ)
+    unsigned* mask_k;     // [B*H*Tk][2*ceil(Tq/64)] words, bit j of word w = query 32 w + j (dK/dV)
 };
 // Mask index of probability (b, h, q, key): ((b H + h) Tq + q) Tkp + key with Tkp = Tk rounded up to a multiple of 4, so
 // that the 4 consecutive keys a lane holds per 16x16 score block (first key % 4 == 0) are 4 consecutive, 4-aligned
@@ -720,6 +723,32 @@ __global__ __launch_bounds__(256, U == 1 ? 2 : 1) void attn_bwd_dkv_bf16(SmxAttn
     }
 }
 
+#include "attention_v2.h"
+
+static bool attn_use_v1() {
+    static const bool v1 = getenv("SMX_ATTN_V1") && getenv("SMX_ATTN_V1")[0] == '1';      // A/B switch: first-generation kernels
+    return v1;
+}
+
+// Words the two bit masks of a dropout call need (mask_q, mask_k); both 0 without dropout on the MFMA path.
+extern "C" int smx_attn_mask_words(const SmxAttnParams* p, int dtype, long long* nq, long long* nk) {
+    *nq = *nk = 0;
+    if (dtype != SMX_BF16 || p->D != 64 || !(p->drop_p > 0.f) || attn_use_v1()) return SMX_OK;
+    *nq = (long long)p->B * p->H * p->Tq * A2_QW(p->Tk);
+    *nk = (long long)p->B * p->H * p->Tk * A2_QW(p->Tq);
+    return SMX_OK;
+}
+
+// Fill p->mask_q / p->mask_k for (drop_p, drop_seed): call once per attention call, before forward; backward reuses them.
+extern "C" int smx_attn_dropout_mask(const SmxAttnParams* pp, hipStream_t stream) {
+    (void)hipGetLastError();
+    SmxAttnParams p = *pp;
+    if (!p.mask_q || !p.mask_k || !(p.drop_p > 0.f) || p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return SMX_EINVAL;
+    const int KW = A2_QW(p.Tk);
+    hipLaunchKernelGGL(attn_mask_kernel, dim3((KW + 3) / 4, (p.Tq + 63) / 64, p.B * p.H), dim3(256), 0, stream, p);
+    SMX_CHECK_LAUNCH();
+}
+
 static int attn_check(const SmxAttnParams& p, int dtype) {
     if (p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return SMX_EINVAL;
     if ((dtype == SMX_F32 || p.D != 64) && (p.D > SIMPLE_MAXD || (p.D & 7))) return SMX_EINVAL;
@@ -738,6 +767,10 @@ extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t
     } else if (dtype == SMX_BF16 && p.D != 64) {   // head widths off the hot path (tiny test configs)
         const int n = p.B * p.H * p.Tq;
         hipLaunchKernelGGL(attn_fwd_simple<bf16_t>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
+    } else if (dtype == SMX_BF16 && !attn_use_v1()) {
+        if (p.drop_p > 0.f && (!p.mask_q || !p.mask_k)) return SMX_EINVAL;       // smx_attn_dropout_mask first
+        const dim3 grid(((p.Tq + 63) / 64) * p.H * p.B);
+        A2_DISPATCH(attn2_fwd, grid);
     } else if (dtype == SMX_BF16) {
         // U = 1 (16 queries per wave): measured faster than U = 2 at T = 499 (occupancy 4 vs 2 waves/SIMD; the
         // kernels are VALU-bound on the softmax, not LDS-bound)
@@ -774,8 +807,15 @@ extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t
     } else if (dtype == SMX_BF16) {
         if (!p.O) return SMX_EINVAL;
         // dQ also writes delta = rowsum(dO * O); the dK/dV kernel reads it (stream order)
-        hipLaunchKernelGGL(attn_bwd_dq_bf16<1>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_bf16<1>, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        if (!attn_use_v1()) {
+            if (p.drop_p > 0.f && (!p.mask_q || !p.mask_k)) return SMX_EINVAL;
+            const dim3 gq(((p.Tq + 63) / 64) * p.H * p.B), gk(((p.Tk + 63) / 64) * p.H * p.B);
+            A2_DISPATCH(attn2_dq, gq);
+            A2_DISPATCH(attn2_dkv, gk);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dq_bf16<1>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL(attn_bwd_dkv_bf16<1>, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
+        }
         if (p.dbias) {
             const long long nb = (long long)p.H * p.Tq * p.Tk;
             hipLaunchKernelGGL(attn_dbias_kernel<bf16_t>, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, p);

@@ -670,8 +670,9 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
     // (sizes below 2^22: the in-kernel index arithmetic divides through fp32 reciprocals)
     if (W >= (1 << 22) || p.M >= (1 << 22) || p.N >= (1 << 22) || p.K >= (1 << 22) || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
         ((p.K & 7) && !(p.a_rc && p.b_rc))) return SMX_EINVAL;
-    // rows-contiguous operands through a batched view: instantiated for the (RC, RC) layout only (conv weight gradients)
-    if (!(p.a_rc && p.b_rc) && ((p.a_rc && p.a.rows_per_batch > 0) || (p.b_rc && p.b.rows_per_batch > 0))) return SMX_EINVAL;
+    // rows-contiguous operands through a batched view: instantiated for the (RC, RC) layout (conv weight gradients) and for
+    // the B operand of the (KC, RC) layout (conv data gradients: the tap-major packed weight read tap by tap)
+    if (p.a_rc && !p.b_rc && p.a.rows_per_batch > 0) return SMX_EINVAL;
     dim3 grid((unsigned)(W < ncu ? W : ncu));
     const int lab = p.tr_mode >> 8;
     const int epi = pp_epi_class(p);
@@ -700,6 +701,12 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
         if (epi == PP_EPI_ACT) PP_GO(false, false, PP_EPI_ACT)
         if (epi == PP_EPI_F32) PP_GO(false, false, PP_EPI_F32)
         PP_GO(false, false, PP_EPI_LINEAR)
+    }
+    if (!p.a_rc && p.b_rc && p.b.rows_per_batch > 0) {
+#define PP_GOV(E) { if (epi == E) p.tr_mode |= 128; pp_launch<false, true, E, true>(p, grid, stream); SMX_CHECK_LAUNCH(); }
+        if (epi == PP_EPI_ACTGRAD) PP_GOV(PP_EPI_ACTGRAD)
+        PP_GOV(PP_EPI_LINEAR)
+#undef PP_GOV
     }
     if (!p.a_rc && p.b_rc) {
         if (epi == PP_EPI_ACTGRAD) PP_GO(false, true, PP_EPI_ACTGRAD)

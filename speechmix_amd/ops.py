@@ -87,8 +87,9 @@ def _pp_applicable(p, dtype):
         return False
     if (p.K & 7) and not (p.a_rc and p.b_rc):
         return False
-    # rows-contiguous operands through a batched view: instantiated for the (RC, RC) layout only (conv weight gradients)
-    if not (p.a_rc and p.b_rc) and ((p.a_rc and p.a.rows_per_batch > 0) or (p.b_rc and p.b.rows_per_batch > 0)):
+    # rows-contiguous operands through a batched view: (RC, RC) (conv weight gradients) and the B operand of (KC, RC)
+    # (conv data gradients)
+    if p.a_rc and not p.b_rc and p.a.rows_per_batch > 0:
         return False
     kst = (p.K + 63) // 64
     per = (kst + p.split_k - 1) // p.split_k
@@ -319,6 +320,17 @@ class AttnDesc:
 
 def attention_fwd(desc, lse, dtype):
     desc.p.lse = _ptr(lse)
+    if desc.p.drop_p > 0 and not desc.p.mask_q:
+        # MFMA path: the keep mask of this call as bit matrices (both orientations), generated once and reused by backward
+        nq, nk = C.c_longlong(0), C.c_longlong(0)
+        L.check(L.lib().smx_attn_mask_words(C.byref(desc.p), dtype, C.byref(nq), C.byref(nk)), "smx_attn_mask_words")
+        if nq.value:
+            dev = lse.device
+            mq = torch.empty(nq.value, dtype=torch.int32, device=dev)
+            mk = torch.empty(nk.value, dtype=torch.int32, device=dev)
+            desc.p.mask_q, desc.p.mask_k = _ptr(mq), _ptr(mk)
+            desc._keep += [mq, mk]
+            L.check(L.lib().smx_attn_dropout_mask(C.byref(desc.p), _stream()), "smx_attn_dropout_mask")
     L.check(L.lib().smx_attention_fwd(C.byref(desc.p), dtype, _stream()), "smx_attention_fwd")
 
 
