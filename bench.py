@@ -26,6 +26,7 @@ CLIP_SECONDS = 10.0
 SAMPLES = 160000
 LABEL_LEN = 32
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md (measured 2495)
+HBM_PEAK_GBPS = 8000.0              # HBM3E spec peak (6.3 TB/s measured achievable), MI355X_MICROARCH.md
 
 
 def synth_batch(B, vocab, rank, device):
@@ -75,6 +76,12 @@ def cpu_baseline(seconds_budget=20.0):
             v.grad = None
         return time.perf_counter() - t0
 
+    def fwd_only(w):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.speechmix_eed_forward(leaves, ec.to_dict(), lc.to_dict(), w, labels=labels, down_scale=2)
+        return time.perf_counter() - t0
+
     one(wave[:, :16000])                       # warm-up on a 1 s clip (allocator, thread pool)
     t1 = one(wave[:, :16000])
     if t1 * 10 > seconds_budget:               # host too slow for even one full clip inside the budget: report the 1 s sample
@@ -85,8 +92,11 @@ def cpu_baseline(seconds_budget=20.0):
     while len(times) < 5 and (not times or time.perf_counter() - t_start + times[-1] < seconds_budget):
         times.append(one(wave))
     t = sorted(times)[len(times) // 2]
+    ft = sorted(fwd_only(wave) for _ in range(3))[1]          # forward-only leg
     return {"value": round(CLIP_SECONDS / t, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": f"1 clip x 10 s, fwd+bwd fp32 (no optimizer), median of {len(times)} after a 1 s warm-up clip"}
+            "sample": f"1 clip x 10 s, fwd+bwd fp32 (no optimizer), median of {len(times)} after a 1 s warm-up clip",
+            "forward_only_value": round(CLIP_SECONDS / ft, 3),
+            "forward_only_sample": "same clip, forward only (no_grad), median of 3"}
 
 
 def spawn_ranks(n, argv):
@@ -114,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout / LayerDrop / SpecAugment off")
+    ap.add_argument("--no-eval-leg", action="store_true", help="skip the extra p=0 pass reported beside the train-mode number")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -173,18 +184,41 @@ def main():
         elapsed = t.item()
     # Roofline pass: the same K steps again with a HIP-event pair around every GEMM launch (on the launch stream).
     # Kept out of the timed pass because ~370 event pairs per step cost ~4 % of the step.
-    prof = None
+    prof = oprof = None
     if not args.no_profile and rank == 0:
-        prof = ops.GemmProfile()
-        ops.GEMM_PROFILE = prof
+        prof, oprof = ops.GemmProfile(), ops.OpProfile()
+        ops.GEMM_PROFILE, ops.OP_PROFILE = prof, oprof
     if not args.no_profile:
         for _ in range(args.steps):
             runner.step(wave, labels)
         torch.cuda.synchronize()
-        ops.GEMM_PROFILE = None
+        ops.GEMM_PROFILE = ops.OP_PROFILE = None
         if world > 1:
             dist.barrier()
     final_loss = float(loss.item())
+    # p = 0 leg ("report both p=0 and reference-default p"): the same K steps with dropout, LayerDrop and
+    # SpecAugment off, timed the same way; reported beside `value`, never instead of it
+    eval_ms = None
+    if not args.eval_mode and not args.no_eval_leg:
+        model.eval()
+        for _ in range(2):
+            runner.step(wave, labels)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.step(wave, labels)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e2], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = t.item()
+        eval_ms = 1e3 * e2 / args.steps
+        model.train()
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -201,6 +235,9 @@ def main():
                                        "32 label tokens, fwd+bwd+allreduce+clip+" + {"adafactor": "Adafactor", "adamw": "AdamW"}[args.optimizer] + ", " + mode,
                            "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
                 "final_loss": round(final_loss, 4)}
+        if eval_ms is not None:
+            line["eval_mode"] = {"ms_per_step": round(eval_ms, 3), "value": round(world * B * CLIP_SECONDS / (eval_ms * 1e-3), 1),
+                                 "note": "p = 0: dropout / LayerDrop / SpecAugment off, all 12 encoder layers every step"}
         if prof is not None:
             summ = prof.summary()
             dom = max(summ, key=lambda k: summ[k]["total_ms"])
@@ -213,7 +250,9 @@ def main():
                                 "flops_per_launch": round(d["flops"] / d["launches"]),
                                 "timing": "HIP events around every launch, K identical steps right after the timed pass"}
             # HBM-side bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
+            if not os.path.exists(pmc):
+                pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
             if os.path.exists(pmc):
                 # PMC keys carry every template argument ("gemm_bf16_pp_kernel<true,true,3,0,false>"): match on the kernel
                 # name and its two layout arguments, launch-weighted over the instantiations
@@ -224,7 +263,23 @@ def main():
                 n = sum(v["launches"] for v in hits)
                 if n:
                     line["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n)
-                    line["roofline"]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    line["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+            # The path's other kernel families against THEIR roofline: HBM-bound ones as algorithmic
+            # bytes / measured time vs the 8 TB/s peak, attention as flops vs the MFMA peak
+            osum = oprof.summary()
+            hbm = {}
+            for k, v in osum.items():
+                ent = {"ms_per_step": round(v["total_ms"] / args.steps, 3), "launches_per_step": round(v["launches"] / args.steps, 1)}
+                if v["bytes"] > 0:
+                    ent.update(GBps=round(v["GBps"], 1), frac_of_hbm_peak=round(v["GBps"] / HBM_PEAK_GBPS, 3))
+                if v["flops"] > 0:
+                    ent.update(tflops=round(v["tflops"], 1), frac_of_mfma_peak=round(v["tflops"] / MFMA_BF16_PEAK_TFLOPS, 3))
+                hbm[k] = ent
+            line["other_kernels"] = hbm
+            all_fl = sum(v["flops"] for v in summ.values())
+            all_ms = sum(v["total_ms"] for v in summ.values())
+            line["all_gemms"] = {"tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1), "ms_per_step": round(all_ms / args.steps, 3),
+                                 "frac_of_mfma_peak": round(all_fl / (all_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
             line["gemm_variants"] = {ops.GemmProfile.name(k): {"tflops": round(v["tflops"], 1),
                                                                   "ms_per_step": round(v["total_ms"] / args.steps, 3),
                                                                   "launches_per_step": v["launches"] // args.steps}

@@ -16,6 +16,7 @@
  */
 #ifndef SPEECHMIX_HIP_H
 #define SPEECHMIX_HIP_H
+#include <stddef.h>
 #include <hip/hip_runtime_api.h>
 #ifdef __cplusplus
 extern "C" {
@@ -188,6 +189,14 @@ typedef struct SmxAfParams {
     float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
 } SmxAfParams;
 int smx_adafactor_step(const SmxAfParams* p, hipStream_t stream);
+
+/* Data-parallel gradient reduction: in-place sum-all-reduce of one contiguous bucket of the flat
+ * gradient buffer over RCCL, on the caller's (side) stream - what HF Trainer -> accelerate -> DistributedDataParallel's
+ * bucketed NCCL all-reduce does for the reference (TF:trainer.py:720-737).  comm: the caller's ncclComm_t; dtype SMX_F32 or
+ * SMX_BF16; n in elements.  RCCL is resolved at run time (no link-time dependency): -38 (ENOSYS) when none can be loaded,
+ * otherwise 0 or RCCL's ncclResult_t.  The Python host issues the same collective through torch.distributed (its process
+ * group owns the communicator); this entry is for hosts that create their own. */
+int smx_allreduce_bucket(void* comm, void* buf, size_t n, int dtype, hipStream_t stream);
 
 /* ABI self-description */
 int smx_sizeof_SmxGemmParams(void);

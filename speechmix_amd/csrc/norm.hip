@@ -263,6 +263,113 @@ __global__ __launch_bounds__(256) void norm_bwd_param_kernel(SmxNormBwdParams p)
     }
 }
 
+// dx AND the gamma / beta partial rows in ONE pass over dy and x (the two-kernel form read both tensors twice: the
+// parameter pass alone was 1.8 % of the training step).  Same work split as the parameter kernel - a wave owns LN_PR rows,
+// all of their loads issued up front - with the row's two reductions and its dx in between; partial rows are reduced over
+// the block's four waves through LDS exactly as there (one partial row pair per block, folded later).
+template <typename T, bool ACT>
+__global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p) {
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + w) * LN_PR;
+    const float invD = 1.0f / (float)p.D;
+    float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        const int c = (lane + 64 * j) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dg[j][e] = db[j][e] = gm[j][e] = bt[j][e] = 0.f;
+        if (c < p.D) {
+            load8(p.gamma + c, gm[j]);
+            if (ACT && p.beta) load8(p.beta + c, bt[j]);
+        }
+    }
+    float xv[LN_PR][LN_NCH][8], dv[LN_PR][LN_NCH][8], mean[LN_PR], rstd[LN_PR];
+#pragma unroll
+    for (int r = 0; r < LN_PR; ++r) {
+        const int row = row0 + r;
+        mean[r] = 0.f; rstd[r] = 0.f;
+        if (row < p.M) {
+            mean[r] = p.rms ? 0.f : p.mean[row];
+            rstd[r] = p.rstd[row];
+        }
+#pragma unroll
+        for (int j = 0; j < LN_NCH; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            if (row < p.M && c < p.D) {
+                load8(reinterpret_cast<const T*>(p.x) + (long long)row * p.D + c, xv[r][j]);
+                load8(reinterpret_cast<const T*>(p.dy) + (long long)row * p.D + c, dv[r][j]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[r][j][e] = dv[r][j][e] = 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LN_PR; ++r) {
+        const int row = row0 + r;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_NCH; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xhat = (xv[r][j][e] - mean[r]) * rstd[r];
+                float d = dv[r][j][e];
+                if (p.drop_p > 0.f)
+                    d *= smx_drop_mul(p.drop_seed, (unsigned)(row * p.D + (lane + 64 * j) * 8 + e), smx_thresh24(p.drop_p),
+                                      1.0f / (1.0f - p.drop_p));
+                if (ACT) d *= act_grad(xhat * gm[j][e] + bt[j][e], p.act);
+                dg[j][e] += d * xhat;
+                db[j][e] += d;
+                const float gg = d * gm[j][e];
+                xv[r][j][e] = xhat;               // (reuse the staging registers: xhat and the scaled gradient)
+                dv[r][j][e] = gg;
+                s1 += gg;
+                s2 += gg * xhat;
+            }
+        s1 = p.rms ? 0.f : wave_sum(s1) * invD;
+        s2 = wave_sum(s2) * invD;
+        if (row < p.M) {
+            T* dx = reinterpret_cast<T*>(p.dx) + (long long)row * p.D;
+            const T* dres = p.dres ? reinterpret_cast<const T*>(p.dres) + (long long)row * p.D : nullptr;
+            float* dpos = p.dpos ? p.dpos + (long long)((row % p.pos_period) + p.pos_offset) * p.D : nullptr;
+#pragma unroll
+            for (int j = 0; j < LN_NCH; ++j) {
+                const int c = (lane + 64 * j) * 8;
+                if (c < p.D) {
+                    float o[8], rr[8];
+                    if (dres) load8(dres + c, rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        o[e] = (dv[r][j][e] - s1 - xv[r][j][e] * s2) * rstd[r];
+                        if (dpos) atomicAdd(dpos + c + e, o[e]);
+                        if (dres) o[e] += rr[e];
+                    }
+                    store8(dx + c, o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_NCH; ++j) {
+        if (64 * 8 * j >= p.D) break;
+        const int c = (lane + 64 * j) * 8;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[w][lane][e] = pass == 0 ? dg[j][e] : db[j][e];
+            __syncthreads();
+            if (w == 0 && c < p.D) {
+                float sum8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum8[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
+                store8(p.partials + ((long long)blockIdx.x * 2 + pass) * p.D + c, sum8);
+            }
+        }
+    }
+}
+
 // second stage of the gamma/beta gradient: column sums over the per-block partials (grid.y-way split rows)
 __global__ void norm_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int D, float* dgamma, float* dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,6 +404,21 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     if ((p.dgamma || p.dbeta) && !p.partials) return SMX_EINVAL;
     const bool act = p.act != SMX_ACT_NONE;
     dim3 grid((p.M + 3) / 4);
+    static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');      // A/B switch
+    if (fuse && (p.dgamma || p.dbeta)) {
+        const int blocks = (p.M + 4 * LN_PR - 1) / (4 * LN_PR);   // workspace: blocks * 2 * D floats
+        if (dtype == SMX_F32) {
+            if (act) hipLaunchKernelGGL((norm_bwd_fused_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((norm_bwd_fused_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, p);
+        } else {
+            if (act) hipLaunchKernelGGL((norm_bwd_fused_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((norm_bwd_fused_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
+        }
+        if (!p.defer_fold)
+            hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((p.D + 63) / 64, blocks >= 64 ? 32 : 1), dim3(64), 0, stream,
+                               p.partials, blocks, p.D, p.dgamma, p.dbeta);
+        SMX_CHECK_LAUNCH();
+    }
     if (dtype == SMX_F32) {
         if (act) hipLaunchKernelGGL((norm_bwd_dx_kernel<float, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((norm_bwd_dx_kernel<float, false>), grid, dim3(256), 0, stream, p);

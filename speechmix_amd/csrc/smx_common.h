@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // ---- error convention: launchers return 0 on success, hipError_t (>0) or negative arg errors ----
 #define SMX_OK 0
 #define SMX_EINVAL (-22)
+#define SMX_ENOSYS (-38)
 #define SMX_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

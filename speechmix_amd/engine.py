@@ -82,7 +82,16 @@ class Engine:
             f = self._folds = None if os.environ.get("SMX_DEFER_FOLDS") == "0" else ops.FoldQueue()
         return f
 
+    def mark(self, name):
+        """Stage boundary marker: with `self.marks` set to a list, records (name, HIP event on the current stream)."""
+        marks = getattr(self, "marks", None)
+        if marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+
     def _stage(self, name):
+        self.mark("bwd:" + name)
         if getattr(self, "_side_active", False):          # join the LM stage's weight-gradient stream
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_active = False
@@ -337,48 +346,73 @@ class Engine:
             self.dgrad(dqkv, self.st.cat(wn), dx, Mq, 3 * d, d, resid=dx_resid)
             return dx
         dq = self.new(Mq, d)
-        dkv = self.new(Mk, 2 * d)
         desc.set("dQ", dq, 0, Tq * d, d)
-        desc.set("dK", dkv, 0, Tk * 2 * d, 2 * d)
-        desc.set("dV", dkv, d, Tk * 2 * d, 2 * d)
+        cat = dkv_accum[2] if (dkv_accum is not None and len(dkv_accum) > 2) else None
+        if cat is not None:
+            # all decoder layers' dK | dV side by side in ONE [Mk, L * 2d] buffer: the gradient wrt the encoder output is then a
+            # single GEMM over K = L * 2d after the last layer (lm_bwd) instead of L accumulating launches of 378 tiles each
+            buf, li, ldc = cat["buf"], cat["layer"], cat["ld"]
+            dkv = buf.view(-1)[li * 2 * d:]
+            desc.set("dK", buf, li * 2 * d, Tk * ldc, ldc)
+            desc.set("dV", buf, li * 2 * d + d, Tk * ldc, ldc)
+        else:
+            ldc = 2 * d
+            dkv = self.new(Mk, 2 * d)
+            desc.set("dK", dkv, 0, Tk * 2 * d, 2 * d)
+            desc.set("dV", dkv, d, Tk * 2 * d, 2 * d)
         ops.attention_bwd(desc, sv["lse"], delta, self.dt)
         if self.tr(qn[0]):
             self.wgrad(dq, sv["x"], self.G(qn[0]), Mq, d, d, gb=self.G(qn[1]) if qn[1] else None)
         if self.tr(kn[0], vn[0]):
-            self.wgrad(dkv, sv["kvsrc"], self.st.cat([kn[0], vn[0]], "g"), Mk, 2 * d, d,
+            self.wgrad(dkv, sv["kvsrc"], self.st.cat([kn[0], vn[0]], "g"), Mk, 2 * d, d, dyv=view(ldc), dy_ld=ldc,
                        gb=self.st.cat([kn[1], vn[1]], "g") if kn[1] else None)
         dx = dx if dx is not None else self.new(Mq, d)
         self.dgrad(dq, self.W(qn[0]), dx, Mq, d, d, resid=dx_resid)
-        if dkv_accum is not None:
+        if dkv_accum is not None and cat is None:
             first = dkv_accum[1]
             self.dgrad(dkv, self.st.cat([kn[0], vn[0]]), dkv_accum[0], Mk, 2 * d, d, resid=None if first else dkv_accum[0])
         return dx
 
     # ------------------------------------------------------------------ transformer layers
+    def _pad_ld(self, F):
+        """Leading dimension of the FFN's [M, F] intermediates.  A row stride that is a multiple of 8 KB (F = 4096 in bf16: the
+        *large* backbones) puts the same column of consecutive rows on ONE HBM channel group: the weight-gradient GEMMs, which
+        read those tensors rows-contiguous (a short run of every row per K step), measured 5x slower there.  64 elements of
+        padding spread the rows over the channels; the GEMMs take the stride through their row views."""
+        es = 2 if self.dt == BF16 else 4
+        return F + 64 if (F * es) % 8192 == 0 and os.environ.get("SMX_PAD_FFN") != "0" else F
+
     def _ffn_fwd(self, h, M, d, F, n1, n2, act, resid, d_act=None, d_out=None):
         """resid + drop_out(fc2(drop_act(act(fc1(h)))))  - both dropouts run inside the GEMM epilogues."""
-        pre = self.new(M, F)
+        Fp = self._pad_ld(F)
+        pre = self.new(M, Fp)
+        f = self.new(M, Fp)
+        fv = view(Fp)
         # bf16: `pre` holds act'(fc1 out) * activation-dropout multiplier - the local derivative the backward GEMM multiplies
         # in - instead of the pre-activation (ops.ACT_SAVE_GRAD: no erf / exp and no dropout hash in the backward epilogue)
         if self.dt == BF16 and act != ACT_NONE and os.environ.get("SMX_SAVE_ACT_GRAD") != "0":
             act = act | ops.ACT_SAVE_GRAD
-        f = self.lin(h, self.W(n1[0]), self.P(n1[1]) if n1[1] else None, M, F, d, act=act, aux_out=pre, drop=d_act)
-        y = self.lin(f, self.W(n2[0]), self.P(n2[1]) if n2[1] else None, M, d, F, resid=resid, drop=d_out)
+        self.lin(h, self.W(n1[0]), self.P(n1[1]) if n1[1] else None, M, F, d, y=f, act=act, aux_out=pre, drop=d_act,
+                 cv=fv if Fp != F else None)
+        y = self.lin(f, self.W(n2[0]), self.P(n2[1]) if n2[1] else None, M, d, F, resid=resid, drop=d_out,
+                     av=fv if Fp != F else None)
         return y, (h, pre, f, d_act, d_out, act)
 
     def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid):
         """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid)."""
         h, pre, f, d_act, d_out, act = sv            # (act as the forward used it: may carry ACT_SAVE_GRAD)
+        Fp = self._pad_ld(F)
+        fv = view(Fp) if Fp != F else None
         gb = self.G(n2[1]) if (n2[1] and self.tr(n2[0])) else None
         dy, fused = self._dropped(dy, d_out, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, d_out, M * d), False)
         if self.tr(n2[0]):
-            self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=None if fused else gb)
-        dpre = self.new(M, F)
-        self.dgrad(dy, self.W(n2[0]), dpre, M, d, F, aux_in=pre, act=act, drop=d_act)
+            self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=None if fused else gb, xv=fv)
+        dpre = self.new(M, Fp)
+        self.dgrad(dy, self.W(n2[0]), dpre, M, d, F, aux_in=pre, act=act, drop=d_act, cv=fv)
         if self.tr(n1[0]):
-            self.wgrad(dpre, h, self.G(n1[0]), M, F, d, gb=self.G(n1[1]) if n1[1] else None)
+            self.wgrad(dpre, h, self.G(n1[0]), M, F, d, gb=self.G(n1[1]) if n1[1] else None, dyv=fv, dy_ld=Fp)
         dh = self.new(M, d)
-        self.dgrad(dpre, self.W(n1[0]), dh, M, F, d, resid=dx_resid)
+        self.dgrad(dpre, self.W(n1[0]), dh, M, F, d, resid=dx_resid, av=fv)
         return dh
 
     def layer_fwd(self, x, B, T, d, H, F, nm, pre_ln, act, eps, causal=False, scale=None, enc=None, Tk=None, rms=False,
@@ -1236,6 +1270,15 @@ class Engine:
             dy = self.ln_bwd(dy, sv["dec_final_ln"], lp + "model.decoder.layer_norm.weight", lp + "model.decoder.layer_norm.bias",
                              Md, d)
         denc = [self.new(Ms, d), True]
+        # cross-attention K/V gradients of all decoder layers side by side (see attn_bwd) when the layers' k|v weights sit at a
+        # uniform stride in the flat store (they do: identical layers), so that ONE rows-contiguous batched view reads them all
+        nL = lc.decoder_layers
+        kv_names = [(self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i))["xattn"] for i in range(nL)]
+        koff = [self.st.offsets[n["k"][0]][0] for n in kv_names]
+        uniform = nL > 1 and all(koff[i + 1] - koff[i] == koff[1] - koff[0] for i in range(nL - 1)) and \
+            os.environ.get("SMX_XATTN_CAT") != "0"
+        if uniform:
+            denc.append(dict(buf=self.new(Ms, nL * 2 * d), layer=0, ld=nL * 2 * d))
         # T5: every layer of a stack adds the stack's relative-position bias (owned by block 0) to its self-attention
         # scores, so the table's gradient is the scatter of the score gradients summed over batch AND layers
         tb = {}
@@ -1248,11 +1291,16 @@ class Engine:
             nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
             if "adapter" in sv["dec_layers"][i]:
                 dy = self.adapter_bwd(dy, sv["dec_layers"][i]["adapter"], lc.encoder_layers + i, Md, d)
+            if uniform:
+                denc[2]["layer"] = i
             dy = self.layer_bwd(dy, sv["dec_layers"][i], nm, pre_ln, act, rms=t5, denc=denc,
                                 dbias=tb["decoder"][1] if "decoder" in tb else None)
             denc[1] = False
         if "decoder" in tb:
             self._t5_bias_bwd(tb["decoder"], sv["t5_buckets"][1])
+        if uniform:          # d enc = [dK|dV of layer 0 | ... | layer L-1] @ [Wk; Wv of layer 0; ...]: one GEMM, K = L * 2d
+            wk0 = self.st.cat([kv_names[0]["k"][0], kv_names[0]["v"][0]])
+            self.dgrad(denc[2]["buf"], wk0, denc[0], Ms, nL * 2 * d, d, bv=view(d, 2 * d, koff[1] - koff[0], 0))
         if not t5:
             pd = lp + "model.decoder."
             pos_n = pd + "embed_positions.weight"
@@ -1326,7 +1374,9 @@ class Engine:
         """Everything ahead of the LM: speech encoder -> (layer-weighted sum) -> length adapters -> enc_to_dec_proj ->
         (text-prompt embeddings prepended).  -> (inputs_embeds [B*S, d_lm], S, state for speech_side_bwd, extras)."""
         B, N = wave.shape
+        self.mark("fwd:start")
         x, ssv = self.speech_fwd(wave, B, N, training)
+        self.mark("fwd:speech")
         T, d = ssv["T"], self.ec.hidden_size
         ws = None
         xin = x
@@ -1393,8 +1443,10 @@ class Engine:
         B = wave.shape[0]
         Ld = dec_ids.shape[1]
         e, S, state, ex = self.speech_side_fwd(wave, training, prompt_ids, weighted_sum)
+        self.mark("fwd:bridge")
         lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
                             training=training if lm_training is None else lm_training)
+        self.mark("fwd:lm")
         self.saved = dict(state, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], Ld=Ld)
         return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=ex["enc_last"],
                     lm_enc_last=lo["lm_enc_last"], inputs_embeds=e, S=S, T=ex["T"], post_adapter=ex["post_adapter"],

@@ -232,13 +232,67 @@ class GemmProfile:
 GEMM_PROFILE = None
 
 
+class OpProfile:
+    """Live timing of the non-GEMM kernel families (HIP events on the launch stream) with their ALGORITHMIC bytes / flops,
+    for the HBM-side lines of bench.py: name -> launches, ms, bytes, flops."""
+
+    def __init__(self):
+        self.pool, self.used, self.recs = [], 0, []
+
+    def span(self, name, nbytes=0.0, flops=0.0):
+        if self.used + 2 > len(self.pool):
+            self.pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(256))
+        e0, e1 = self.pool[self.used], self.pool[self.used + 1]
+        self.used += 2
+        self.recs.append((name, e0, e1, float(nbytes), float(flops)))
+        return e0, e1
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, nb, fl in self.recs:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, bytes=0.0, flops=0.0))
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nb
+            d["flops"] += fl
+        for d in out.values():
+            sec = d["total_ms"] * 1e-3
+            d["GBps"] = d["bytes"] / sec / 1e9 if sec > 0 else 0.0
+            d["tflops"] = d["flops"] / sec / 1e12 if sec > 0 else 0.0
+        return out
+
+
+OP_PROFILE = None
+
+
+class _Span:
+    """with _Span(name, bytes, flops): ...   (no-op unless OP_PROFILE is set)"""
+
+    def __init__(self, name, nbytes=0.0, flops=0.0):
+        self.ev = OP_PROFILE.span(name, nbytes, flops) if OP_PROFILE is not None else None
+
+    def __enter__(self):
+        if self.ev:
+            self.ev[0].record()
+
+    def __exit__(self, *a):
+        if self.ev:
+            self.ev[1].record()
+        return False
+
+
+def _es(dtype):
+    return 2 if dtype == BF16 else 4
+
+
 def norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dtype, eps=1e-5, rms=False, act=ACT_NONE, pos=None, pos_period=0,
              pos_offset=0, xsum_out=None, drop=None):
     p = L.NormParams(_ptr(x), _ptr(pos), _ptr(xsum_out), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd),
                      M, D, pos_period, pos_offset, int(rms), act, eps)
     if drop is not None and drop[0] > 0:
         p.drop_p, p.drop_seed = drop
-    L.check(L.lib().smx_norm_fwd(C.byref(p), dtype, _stream()), "smx_norm_fwd")
+    with _Span("norm_fwd", M * D * _es(dtype) * (3 if xsum_out is not None else 2)):
+        L.check(L.lib().smx_norm_fwd(C.byref(p), dtype, _stream()), "smx_norm_fwd")
 
 
 class FoldQueue:
@@ -285,7 +339,8 @@ def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms
         p.drop_p, p.drop_seed = drop
     if folds is not None and ws is not None:
         p.defer_fold = 1
-    L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
+    with _Span("norm_bwd", M * D * _es(dtype) * (4 if dres is not None else 3)):
+        L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
     if folds is not None and ws is not None:
         assert rows == L.lib().smx_norm_bwd_partial_rows(M)
         if dgamma is not None:
@@ -331,12 +386,16 @@ def attention_fwd(desc, lse, dtype):
             desc.p.mask_q, desc.p.mask_k = _ptr(mq), _ptr(mk)
             desc._keep += [mq, mk]
             L.check(L.lib().smx_attn_dropout_mask(C.byref(desc.p), _stream()), "smx_attn_dropout_mask")
-    L.check(L.lib().smx_attention_fwd(C.byref(desc.p), dtype, _stream()), "smx_attention_fwd")
+    pp = desc.p
+    with _Span("attention_fwd", 0, 4.0 * pp.B * pp.H * pp.Tq * pp.Tk * pp.D * (0.5 if pp.causal else 1.0)):
+        L.check(L.lib().smx_attention_fwd(C.byref(desc.p), dtype, _stream()), "smx_attention_fwd")
 
 
 def attention_bwd(desc, lse, delta, dtype, dbias=None):
     desc.p.lse, desc.p.delta, desc.p.dbias = _ptr(lse), _ptr(delta), _ptr(dbias)
-    L.check(L.lib().smx_attention_bwd(C.byref(desc.p), dtype, _stream()), "smx_attention_bwd")
+    pp = desc.p
+    with _Span("attention_bwd", 0, 10.0 * pp.B * pp.H * pp.Tq * pp.Tk * pp.D * (0.5 if pp.causal else 1.0)):
+        L.check(L.lib().smx_attention_bwd(C.byref(desc.p), dtype, _stream()), "smx_attention_bwd")
 
 
 def attn_bias_scatter(dbias, bucket, dtable, H, Tq, Tk, nbuckets):
@@ -361,13 +420,15 @@ def conv0_params(wave, w, cbias, gamma, beta, stats, y, B, N, Cc, k, stride, T0,
 
 
 def conv0_fwd(p, dtype):
-    L.check(L.lib().smx_conv0_fwd(C.byref(p), dtype, _stream()), "smx_conv0_fwd")
+    with _Span("conv0_fwd", p.B * p.T0 * p.C * _es(dtype) + 2 * p.B * p.N * 4):      # activation written once, waveform read twice
+        L.check(L.lib().smx_conv0_fwd(C.byref(p), dtype, _stream()), "smx_conv0_fwd")
 
 
 def conv0_bwd(p, dy, bstats, dw, dcbias, dgamma, dbeta, dtype):
     p.dy, p.bstats, p.dw, p.dcbias, p.dgamma, p.dbeta = _ptr(dy), _ptr(bstats), _ptr(dw), _ptr(dcbias), _ptr(dgamma), \
         _ptr(dbeta)
-    L.check(L.lib().smx_conv0_bwd(C.byref(p), dtype, _stream()), "smx_conv0_bwd")
+    with _Span("conv0_bwd", p.B * p.T0 * p.C * _es(dtype) + 2 * p.B * p.N * 4):      # dy read once
+        L.check(L.lib().smx_conv0_bwd(C.byref(p), dtype, _stream()), "smx_conv0_bwd")
 
 
 def cast_from_f32(src, dst, n, dtype):
@@ -453,7 +514,9 @@ def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, 
                   kld=None, kld_scale=0.0):
     p = L.CEParams(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(argmax), _ptr(dlogits), _ptr(lse), M, V, ldl, ldd, gscale,
                    _ptr(logits_t), _ptr(kld), kld_scale)
-    L.check(L.lib().smx_cross_entropy(C.byref(p), dtype, _stream()), "smx_cross_entropy")
+    nb = M * V * (8 + (_es(dtype) if dlogits is not None else 0))          # two passes over the fp32 logits + the gradient written
+    with _Span("cross_entropy", nb):
+        L.check(L.lib().smx_cross_entropy(C.byref(p), dtype, _stream()), "smx_cross_entropy")
 
 
 def add(a, b, out, n, dtype):
@@ -545,6 +608,12 @@ class AdafactorPlan:
                 for c0 in range(0, numel, self.VEC_TILE):
                     tiles.append((t, 0, 0, 1, c0, min(self.VEC_TILE, numel - c0), 1, 1))
                 col_n += numel
+        self._numel = []
+        for off, shape in tensors:
+            n = 1
+            for dd in shape:
+                n *= dd
+            self._numel.append((off, n))
         self.ntiles, self.nsegs = len(tiles), len(segs)
         self.row_n, self.col_n = max(row_n, 1), max(col_n, 1)
         dev = device
@@ -591,7 +660,9 @@ class AdafactorPlan:
         o.beta2t, o.gnorm_sq = _ptr(self.beta2t), _ptr(gnorm_sq)
         o.racc_n, o.cacc_n, o.ntensors, o.ntiles, o.nsegs = self.row_n, self.col_n, self.n, self.ntiles, self.nsegs
         o.lr, o.eps1, o.clip_threshold, o.grad_scale, o.max_grad_norm = lr, eps1, clip_threshold, grad_scale, max_grad_norm
-        L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
+        nact = float(sum(t[1] for t, a in zip(self._numel, act) if a)) if hasattr(self, "_numel") else 0.0
+        with _Span("adafactor_step", 22.0 * nact):       # g read 3x, p read + written, bf16 copy written (csrc/adafactor.hip)
+            L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
 
 
 def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):
@@ -600,6 +671,11 @@ def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):
 
 
 def reduce_slabs(slabs, nsplit, n, stride, dst, accumulate=True):
+    with _Span("reduce_slabs", 4.0 * n * (nsplit + (2 if accumulate else 1))):
+        _reduce_slabs(slabs, nsplit, n, stride, dst, accumulate)
+
+
+def _reduce_slabs(slabs, nsplit, n, stride, dst, accumulate):
     L.check(L.lib().smx_reduce_slabs(C.c_void_p(_ptr(slabs)), nsplit, C.c_longlong(n), C.c_longlong(stride),
                                      C.c_void_p(_ptr(dst)), int(accumulate), _stream()), "smx_reduce_slabs")
 

@@ -107,3 +107,13 @@ def test_pingpong_gemm_isa_has_no_spills_and_no_queue_drain():
             elif not in_asm and "s_waitcnt" in l and "vmcnt" in l:
                 bad.append(l.strip())
         assert not bad, f"{name}: compiler-inserted VMEM wait inside the K loop: {bad}"
+
+
+def test_allreduce_bucket_entry_validates_and_reports_missing_rccl_without_crashing(lib):
+    """smx_allreduce_bucket: exported, validates its arguments, and an empty bucket is a no-op.
+    (A real collective needs >= 1 GPU and a communicator: tests/test_gpu_r2.py drives it through RCCL on the GPU box.)"""
+    fn = lib.smx_allreduce_bucket
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert fn(None, None, 16, 0, None) == -22                    # no communicator / buffer
+    assert fn(C.c_void_p(1), C.c_void_p(1), 0, 0, None) == 0      # empty bucket
+    assert fn(C.c_void_p(1), C.c_void_p(1), 16, 7, None) == -22   # unknown dtype

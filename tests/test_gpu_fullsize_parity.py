@@ -44,6 +44,24 @@ def test_fullsize_bf16_matches_oracle_within_measured_bounds():
     assert r["argmax_checked"] > 0 and r["argmax_equal"]
 
 
+def test_fp32_path_is_bitwise_clip_independent_at_real_dimensions():
+    """Every clip is independent in the reference's arithmetic (no batch statistics anywhere: SURVEY.md section 8e) - the
+    property data parallelism rests on.  On the fp32 path it holds BIT FOR BIT: clip 0 alone and clip 0 inside a batch of 4
+    give identical hidden states and logits (on the bf16 path it holds up to rounding-flip noise, see test_gpu_fullsize*.py)."""
+    import contextlib, io
+    from speechmix_amd.model import SpeechMixEED
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", down_scale=2, compute_dtype="fp32", init_seed=0).eval()
+    g = torch.Generator().manual_seed(1234)
+    wave = (torch.randn(4, 48000, generator=g) * 0.1).clamp_(-1, 1).cuda()
+    labels = torch.randint(4, model.decoder_model.config.vocab_size, (4, 8), generator=g).cuda()
+    with torch.no_grad():
+        a = model(wave, labels=labels, return_model_detail=True)
+        b = model(wave[:1], labels=labels[:1], return_model_detail=True)
+    for k in ("encoder_last_hidden_state", "inputs_embeds", "lm_encoder_last_hidden", "raw_logits"):
+        assert torch.equal(a[k][:1], b[k]), k
+
+
 @pytest.mark.parametrize("M,N,K", [(15968, 768, 768), (15968, 2304, 768), (15968, 3072, 768), (15968, 768, 3072)])
 def test_bf16_gemm_kernels_vs_fp32_reference_at_model_shapes(M, N, K):
     """Both production kernels (128x128 LDS-DMA and 256x256 ping-pong), all three operand layouts the model uses

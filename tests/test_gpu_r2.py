@@ -257,3 +257,39 @@ def test_position_table_overrun_raises_like_hf():
         model2.generate(inp["input_values"], max_length=40)
     with pytest.raises(IndexError):
         model2(inp["input_values"], labels=torch.full((2, 6), 500))         # label id >= vocab
+
+
+def test_allreduce_bucket_c_entry_runs_a_real_rccl_collective():
+    """smx_allreduce_bucket(ncclComm_t, buf, n, dtype, stream) with a communicator created the way a
+    C host would (ncclGetUniqueId + ncclCommInitRank, one rank on this GPU), on a side stream: the in-place sum over one
+    rank must leave the bucket unchanged, for fp32 and bf16 buckets of the flat gradient buffer."""
+    import ctypes as C
+    from speechmix_amd import _lib as L
+    lib = L.lib()
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("librccl.so")
+
+    class UID(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UID()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        fn = lib.smx_allreduce_bucket
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        side = torch.cuda.Stream()
+        for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+            x = torch.randn(1 << 20, device="cuda").to(dt)
+            ref = x.clone()
+            side.wait_stream(torch.cuda.current_stream())
+            assert fn(comm, C.c_void_p(x.data_ptr()), x.numel(), code, C.c_void_p(side.cuda_stream)) == 0
+            side.synchronize()
+            assert torch.equal(x, ref)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -1,35 +1,51 @@
-"""Run a BASELINE.json config through the native step runner for a few steps (memory / shape / speed check)."""
-import sys, os, time, contextlib, io
+"""Run a BASELINE.json config through the native step runner and print ONE JSON line (committed under profiles/ by
+tools/run_cfg_benches.sh).   python tools/gpu_bench_cfg.py CFG [B] [STEPS] [train|eval]
+CFG 2: wav2vec2-base -> bart-base ds 2;  4: hubert-large-ll60k -> mbart-large-50 ds 8;  5: SpeechMixSelf wav2vec2-large -> t5-large,
+share_layer_ratio 0.5, ds 8 (LM frozen, text_input_ids [B, 33]).  Synthetic 10 s clips, 32 label tokens, bf16, Adafactor."""
+import contextlib, io, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from speechmix_amd.model import SpeechMixEED, SpeechMixSelf
 from speechmix_amd.trainer import StepRunner
 
-cfg = sys.argv[1]
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-with contextlib.redirect_stdout(io.StringIO()):
-    if cfg == "4":
-        model = SpeechMixEED("hubert_large_ll60k", "facebook/mbart-large-50", down_scale=8)
-    elif cfg == "5":
-        model = SpeechMixSelf("wav2vec2_large_960", "t5-large", share_layer_ratio=0.5, down_scale=8)
-    else:
-        model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", down_scale=2)
-model.eval()
-V = model.decoder_model.config.vocab_size
-g = torch.Generator().manual_seed(0)
-wave = (torch.randn(B, 160000, generator=g) * 0.1).clamp_(-1, 1).cuda()
-labels = torch.randint(4, V, (B, 32), generator=g).cuda()
-text = torch.randint(4, V, (B, 33), generator=g).cuda() if cfg == "5" else None
-runner = StepRunner(model, lr=1e-5, optimizer=os.environ.get("SMX_OPT", "adafactor"))
-print(f"cfg {cfg}: params {model.store.total/1e6:.1f} M, trainable ranges {len(runner.ranges)}", flush=True)
-for i in range(2):
-    loss = runner.step(wave, labels, text_input_ids=text)
-torch.cuda.synchronize()
-print("warm loss", loss.item(), "mem GB", torch.cuda.max_memory_allocated() / 1e9, flush=True)
-t0 = time.perf_counter()
-for i in range(steps):
-    loss = runner.step(wave, labels, text_input_ids=text)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps
-print(f"cfg {cfg}: {dt*1e3:.1f} ms/step  {B*10/dt:.0f} audio-s/s  loss {loss.item():.4f}")
+NAMES = {"2": "SpeechMixEED wav2vec2-base + bart-base, down_scale 2",
+         "4": "SpeechMixEED hubert-large-ll60k + mbart-large-50, down_scale 8",
+         "5": "SpeechMixSelf wav2vec2-large + t5-large, share_layer_ratio 0.5, down_scale 8 (LM frozen)"}
+
+
+def build(cfg):
+    with contextlib.redirect_stdout(io.StringIO()):
+        if cfg == "4":
+            return SpeechMixEED("hubert_large_ll60k", "facebook/mbart-large-50", down_scale=8)
+        if cfg == "5":
+            return SpeechMixSelf("wav2vec2_large_960", "t5-large", share_layer_ratio=0.5, down_scale=8)
+        return SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", down_scale=2)
+
+
+if __name__ == "__main__":
+    cfg = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    mode = sys.argv[4] if len(sys.argv) > 4 else "train"
+    model = build(cfg)
+    model.train(mode == "train")
+    V = model.decoder_model.config.vocab_size
+    g = torch.Generator().manual_seed(0)
+    wave = (torch.randn(B, 160000, generator=g) * 0.1).clamp_(-1, 1).cuda()
+    labels = torch.randint(4, V, (B, 32), generator=g).cuda()
+    text = torch.randint(4, V, (B, 33), generator=g).cuda() if cfg == "5" else None
+    runner = StepRunner(model, lr=1e-5, optimizer=os.environ.get("SMX_OPT", "adafactor"))
+    for i in range(3):
+        loss = runner.step(wave, labels, text_input_ids=text)
+    torch.cuda.synchronize()
+    mem = torch.cuda.max_memory_allocated() / 1e9
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = runner.step(wave, labels, text_input_ids=text)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": int(cfg), "workload": NAMES[cfg], "mode": mode, "batch": B, "clip_seconds": 10.0, "steps": steps,
+                      "ms_per_step": round(dt * 1e3, 2), "audio_s_per_s": round(B * 10 / dt, 1), "dtype": "bf16",
+                      "optimizer": "adafactor", "params_M": round(model.store.total / 1e6, 1), "peak_mem_GB": round(mem, 1),
+                      "final_loss": round(loss.item(), 4), "n_gpus": 1,
+                      "ffn_ld_padding": os.environ.get("SMX_PAD_FFN", "1") != "0"}), flush=True)
