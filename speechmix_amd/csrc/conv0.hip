@@ -386,6 +386,13 @@ __global__ __launch_bounds__(256) void conv0_bwd_w_kernel(SmxConv0Params p) {
     }
 }
 
+#include "conv0_mfma.h"
+
+static bool conv0_use_mfma(const SmxConv0Params& p, int dtype) {
+    static const bool off = getenv("SMX_CONV0_MFMA") && getenv("SMX_CONV0_MFMA")[0] == '0';      // A/B switch
+    return !off && dtype == SMX_BF16 && C0M_OK(p);
+}
+
 static int conv0_check(const SmxConv0Params& p) {
     if (p.B <= 0 || p.C <= 0 || (p.C & 7) || p.C > 512 || p.k > C0_MAXK || p.k <= 0 || p.stride <= 0 || p.stride > 8) return SMX_EINVAL;
     if (p.T0 != (p.N - p.k) / p.stride + 1 || p.T0 <= 0) return SMX_EINVAL;
@@ -421,12 +428,17 @@ extern "C" int smx_conv0_fwd(const SmxConv0Params* pp, int dtype, hipStream_t st
     if (p.group) {
         if (!p.stats || !p.gamma || !p.beta || !p.partials) return SMX_EINVAL;
         conv0_reduction_geometry(p);
-        C0_LAUNCH_K(conv0_stats_kernel, dim3(p.nb, p.B), p, stream);
+        if (conv0_use_mfma(p, dtype)) hipLaunchKernelGGL(c0m_stats_kernel, dim3(p.nb, p.B), dim3(256), 0, stream, p);
+        else C0_LAUNCH_K(conv0_stats_kernel, dim3(p.nb, p.B), p, stream);
         const int n = p.B * p.C * 2;
         hipLaunchKernelGGL(conv0_stats_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p.partials, p.stats, p.B, p.C, p.nb);
     }
     p.tiles_per_block = 4;
     const dim3 grid((ntiles + 3) / 4, p.B);
+    if (p.group && conv0_use_mfma(p, dtype)) {
+        hipLaunchKernelGGL(c0m_apply_kernel, grid, dim3(256), 0, stream, p);
+        SMX_CHECK_LAUNCH();
+    }
     if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_apply_kernel, float, grid, p, stream);
     else C0_LAUNCH_TK(conv0_apply_kernel, bf16_t, grid, p, stream);
     SMX_CHECK_LAUNCH();
@@ -447,7 +459,8 @@ extern "C" int smx_conv0_bwd(const SmxConv0Params* pp, int dtype, hipStream_t st
         float* xpart = p.partials + (long long)p.B * C0_NBMAX * p.C * (p.k + 2);
         float* contrib = xpart + (long long)p.B * C0_NBMAX * (p.k * p.k + p.k);
         hipLaunchKernelGGL(conv0_xcorr_kernel, grid, dim3(256), 0, stream, p, xpart);
-        if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_group_kernel, float, grid, p, stream);
+        if (conv0_use_mfma(p, dtype)) hipLaunchKernelGGL(c0m_bwd_kernel, grid, dim3(256), 0, stream, p);
+        else if (dtype == SMX_F32) C0_LAUNCH_TK(conv0_bwd_group_kernel, float, grid, p, stream);
         else C0_LAUNCH_TK(conv0_bwd_group_kernel, bf16_t, grid, p, stream);
         hipLaunchKernelGGL(conv0_bwd_group_finalize_kernel, dim3((p.C + 15) / 16, p.B), dim3(256), 0, stream, p, xpart, contrib);
         hipError_t e = hipGetLastError();

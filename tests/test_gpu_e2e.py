@@ -28,7 +28,9 @@ def _err(a, b):
 
 
 @pytest.mark.parametrize("case", ["eed_w2v2_bart", "eed_hubert_mbart"])
-@pytest.mark.parametrize("dtype,tol_act,tol_logit,tol_grad", [("fp32", 2e-4, 1e-3, 2e-3), ("bf16", 1.5e-1, 1.5e-1, 2.5e-1)])
+# bf16 bounds = 3 x what the path measures on these fixtures on the MI355X (round 2: activations <= 5.5e-2, logits <= 3.9e-3,
+# loss <= 1.9e-4, worst gradient 3.5e-2 of its tensor's max); the same rule at the real dimensions: test_gpu_fullsize_parity.py
+@pytest.mark.parametrize("dtype,tol_act,tol_logit,tol_grad", [("fp32", 2e-4, 1e-3, 2e-3), ("bf16", 1.6e-1, 1.2e-2, 1.1e-1)])
 def test_eed_forward_backward_matches_reference(case, dtype, tol_act, tol_logit, tol_grad):
     model, inp, gold, m = _build(case, dtype)
     out = model(inp["input_values"], labels=inp["labels"], return_model_detail=True)
@@ -105,7 +107,8 @@ def test_frozen_lm_gets_no_grads_and_requires_grad_toggle():
     assert e < 2e-3 * gold["grad::enc_to_dec_proj.weight"].abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize("dtype,tol,tol_grad", [("fp32", 1e-3, 3e-3), ("bf16", 1.5e-1, 2.5e-1)])
+# bf16: measured logits 2.9e-2, loss 4.8e-3, gradients 1.6e-2 of max -> bounds 3 x
+@pytest.mark.parametrize("dtype,tol,tol_grad", [("fp32", 1e-3, 3e-3), ("bf16", 9e-2, 5e-2)])
 def test_speechmix_self_t5_losses_and_grads(dtype, tol, tol_grad):
     """SpeechMixSelf (wav2vec2 + T5, share 0.5, ds 4): CE + KLD + MSE and gradients vs the reference's cal_loss."""
     from speechmix_amd.model import SpeechMixSelf
