@@ -68,8 +68,9 @@ _TUNED = {}
 # - RCCL's all-reduce of the gradient buckets on the side stream during backward - takes CUs away, and the displaced
 # workgroups then run as a second round (up to 2x the launch time), where the 4-workgroup/CU kernel only loses a quarter of
 # those CUs.  StepRunner clears this flag when gradients are all-reduced concurrently (world size > 1); forward launches
-# (nothing runs beside them) keep the choice.  SMX_GEMM_PP=1 overrides.
-PP_CONCURRENT_BACKWARD_OK = True
+# (nothing runs beside them) keep the choice.  SMX_GEMM_PP=1 overrides; SMX_PP_BACKWARD=0 clears the flag on a single GPU
+# (what the policy costs there: DESIGN.md section 5).
+PP_CONCURRENT_BACKWARD_OK = os.environ.get("SMX_PP_BACKWARD", "1") != "0"
 IN_BACKWARD = False
 
 
