@@ -256,7 +256,7 @@ struct PPIssue {
         b.init(reinterpret_cast<const bf16_t*>(p.B) + it.zb, p.b, it.n0, p.N, k0, tid);
     }
     // KIND: 0 AH0, 1 BH0, 2 BH1, 3 AH1 (then move to the next K tile).  Returns false when the stream has ended.
-    template <int KIND>
+    template <int KIND, bool FREEZE = false>       // FREEZE (ablation builds): every K tile re-reads the item's first one
     __device__ __forceinline__ bool issue(int tid) {
         if (!live) return false;
         const unsigned st = lds0 + (unsigned)(seq & 1) * PP_STAGE;
@@ -269,7 +269,7 @@ struct PPIssue {
             if (++kt == nk) {
                 q += qstep;
                 load_item(tid);
-            } else {
+            } else if (!FREEZE) {
                 k0 += BK;
                 a.advance();
                 b.advance();
@@ -301,7 +301,7 @@ template <int PH, bool A_RC, bool B_RC, bool BVIEW, int LAB>
 __device__ __forceinline__ void pp_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4][2],
                                          bf16x8_t (&fb0)[2][2], bf16x8_t (&fb1)[2][2], PPIssue<A_RC, B_RC, BVIEW>& is,
                                          const char* cur, int tid, int lane, int wr, int wc, int wmode) {
-    // LAB (ablation builds only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 16 no epilogue
+    // LAB (ablation builds only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 16 no epilogue, 64 fills re-read one K tile (L2-resident)
     // ---- load segment: register sub-tile reads + one unit of LDS-DMA, then the counted wait for the NEXT phase's unit
     if constexpr (!(LAB & 2)) {
         if (PH == 0) {
@@ -330,7 +330,7 @@ __device__ __forceinline__ void pp_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4]
         // wmode 0: counted wait.  1: this item's last phase - drain, so that the epilogue's stores (same counter, in-order)
         // do not sit between the prefetched units and the waits that retire them.  2: first K tile after a drain - the
         // units these four phases would retire were covered by it.
-        const bool issued = is.template issue<(PH + 2) & 3>(tid);
+        const bool issued = is.template issue<(PH + 2) & 3, (LAB & 64) != 0>(tid);
         if (wmode == 2) {
         } else if (issued && wmode == 0) {
             PP_WAITV(8);
@@ -688,7 +688,7 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_bf16_pp_kernel<false, false, 0, L>), grid, dim3(512), ldsz, stream, p);                   \
         break;
         switch (lab) {
-            PP_LABV(16) PP_LABV(17) PP_LABV(18) PP_LABV(19)
+            PP_LABV(16) PP_LABV(17) PP_LABV(18) PP_LABV(19) PP_LABV(80) PP_LABV(64)
             default: return SMX_EINVAL;
         }
         SMX_CHECK_LAUNCH();
