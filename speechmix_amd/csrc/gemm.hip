@@ -186,11 +186,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
 // zero page through the per-lane source pointer.  One 32-KB LDS buffer and <=128 registers per lane:
 // 4 workgroups per CU hide each other's fill latency (two barriers per K step).
 // ------------------------------------------------------------------------------------------------
-template <bool RC>
+template <bool RC, int NPASS = 4>
 struct DmaLoader {
+    static constexpr int NP = RC ? 4 : NPASS;      // KC: passes of 32 rows (4: 128-row tile, 2: 64-row tile)
     // Minimal per-thread state (this kernel lives on a 128-register budget): KC keeps one 32-bit element offset per
     // pass (-1: row out of range -> zero page); RC recomputes its source address from k every step.
-    int off[4];
+    int off[NP];
     int kc;                  // KC: my k offset inside a step (source chunk * 8)
     const bf16_t* base;
     const bf16_t* zero;
@@ -202,7 +203,7 @@ struct DmaLoader {
         kc = 0;
         if (!RC) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const int rl = p * 32 + wave * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ ((rl >> 1) & 7);
                 if (p == 0) kc = c * 8;       // identical for all p: (rl>>1)&7 only depends on wave*8+(lane>>3)
@@ -218,7 +219,7 @@ struct DmaLoader {
         if (!RC) {
             const bool kin = k0 + kc < K;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const bf16_t* src = (kin && off[p] >= 0) ? base + off[p] + k0 : zero;
                 if (ASM) glds16_asm(src, tile + (p * 32 + wave * 8) * 128);
                 else glds16(src, tile + (p * 32 + wave * 8) * 128);
@@ -240,7 +241,8 @@ struct DmaLoader {
 
 // acc[i][j]: 16x16 block (rows mw0 + 16 i .., cols nw0 + 16 j ..) of this wave's 64x64 sub-tile; wbuf: 8 KB of LDS
 // owned by this wave (no other wave touches it between the caller's barriers).
-__device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
+template <int NH = 2>       // NH: 32-row halves of the wave's sub-tile (2: 64 x 64, 1: 32 x 64)
+__device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t (&acc)[2 * NH][4], char* wbuf, int mw0, int nw0,
                                                 long long zc, long long zbias, long long ze, int lane) {
     const int i16 = lane & 15, g = lane >> 4;
     const int rr = lane >> 3, cc = lane & 7;
@@ -255,7 +257,7 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -285,8 +287,8 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
 // (a quarter of a K = 768 launch: the workgroups of a CU reach their epilogues together and are bound by VALU issue).
 // EPIX: class of gemm_common.h, or 4 / 5 = ACT / ACTGRAD whose side tensor is the local derivative (SMX_ACT_SAVE_GRAD),
 // or 6 = F32 without the accumulate form
-template <int EPIX, int QBX = 0>       // QBX: row visits per batch (0: by class)
-__device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32x4_t (&acc)[4][4], char* wbuf, int mw0, int nw0,
+template <int EPIX, int QBX = 0, int NH = 2>       // QBX: row visits per batch (0: by class); NH: 32-row halves of the wave's sub-tile
+__device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32x4_t (&acc)[2 * NH][4], char* wbuf, int mw0, int nw0,
                                                      long long zc, long long zbias, long long ze, int lane) {
     constexpr int EPI = EPIX == 4 ? PP_EPI_ACT : EPIX == 5 ? PP_EPI_ACTGRAD : EPIX == 6 ? PP_EPI_F32 : EPIX;
     constexpr bool sg = EPIX == 4 || EPIX == 5;
@@ -329,7 +331,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
         for (int qi = 0; qi < QB; ++qi) side_nxt[qi] = side_load(0, qi);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -369,7 +371,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
             if constexpr (SIDE) {
                 constexpr int NB = 4 / QB;                               // batches per half
                 const int b1 = h * NB + q0 / QB + 1;                     // (compile-time after unrolling)
-                if (b1 < 2 * NB) {
+                if (b1 < NH * NB) {
 #pragma unroll
                     for (int qi = 0; qi < QB; ++qi) side_nxt[qi] = side_load(b1 / NB, (b1 % NB) * QB + qi);
                 }
@@ -454,13 +456,18 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
 #ifndef TR1_MINWG
 #define TR1_MINWG 4
 #endif
-template <bool A_RC, bool B_RC, int EPI = -1>       // EPI: epilogue class (gemm_common.h; 4 / 5: see epilogue_staged_fast) on aligned views, -1: generic
+// BMH: 64-row halves of the output tile.  2: 128 x 128.  1: 64 x 128 (wave sub-tile 32 x 64) for launches whose 128-row tiling
+// leaves most of the 1024 resident workgroup slots empty (the LM's M = 7 968 and M = 1 024 GEMMs): twice the workgroups,
+// each with half the A fill and half the MFMAs per K step.  K-contiguous A operands only.
+template <bool A_RC, bool B_RC, int EPI = -1, int BMH = 2>       // EPI: epilogue class (gemm_common.h; 4 / 5: see epilogue_staged_fast) on aligned views, -1: generic
 __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmParams p) {
+    static_assert(BMH == 2 || !A_RC, "64-row tiles: K-contiguous A only");
+    constexpr int TBM = 64 * BMH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.drop_seed == 0xdead0001u) return;      // LAB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + TBM - 1) / TBM;
     const int nwg = ntn * ntm;
     // Split-K launches (weight gradients: few output tiles, very long K) are bound by the operand fills.  All tiles of
     // one K slice read the same rows of A and B, so they should share an L2.  Workgroups go to XCDs round-robin in
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
         tm = rem / gsz;
         tn = first + (rem - tm * gsz);
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * BN;
     const int zb = z / p.split_k, zs = z - zb * p.split_k;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)zb * p.batch_a;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)zb * p.batch_b;
@@ -505,14 +512,14 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
     const int ks0 = zs * per, ks1 = min(ksteps_total, ks0 + per);
     if (ks0 >= ks1 && p.split_k > 1 && p.atomic == 1) continue;
 
-    DmaLoader<A_RC> la;
+    DmaLoader<A_RC, 2 * BMH> la;
     DmaLoader<B_RC> lb;
     la.init(A, p.a, m0, p.M, ks0 * BK, tid);
     lb.init(B, p.b, n0, p.N, ks0 * BK, tid);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[2 * BMH][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * BMH; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -524,20 +531,20 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
         __syncthreads();                 // (the compiler drains the LDS-DMA queue before the barrier)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t fa[4], fb[4];
+            bf16x8_t fa[2 * BMH], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = load_frag<A_RC>(tA, wm * 64 + i * 16, kk, lane, 1);
+            for (int i = 0; i < 2 * BMH; ++i) fa[i] = load_frag<A_RC>(tA, wm * 32 * BMH + i * 16, kk, lane, 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_RC>(tB, wn * 64 + j * 16, kk, lane, 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2 * BMH; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();                 // everyone is done reading before the next fill overwrites the tile
     }
-    if (p.drop_seed == 0xdead0002u) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[tid] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }   // LAB
+    if (p.drop_seed == 0xdead0002u) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[tid] = acc[1][1][1] + acc[2 * BMH - 1][2][2] + acc[2 * BMH - 1][3][3]; return; }   // LAB
     // the K loop ended on a barrier: the tile buffers are free, each wave transposes through its own 8-KB slice.
     // The lane id and the parameter block are re-read behind an opaque asm: everything the epilogue derives from them
     // (LDS addresses, row offsets, flags) is then computed HERE instead of being hoisted above the K loop, where it would
@@ -551,9 +558,9 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
         asm volatile("" : "+s"(ka));
         const SmxGemmParams& pe = *(const SmxGemmParams*)ka;
         if constexpr (EPI >= 0)
-            epilogue_staged_fast<EPI, (EPI == 6 && !A_RC && B_RC) ? 1 : 0>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+            epilogue_staged_fast<EPI, (EPI == 6 && !A_RC && B_RC) ? 1 : 0, BMH>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 32 * BMH, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
         else
-            epilogue_staged(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+            epilogue_staged<BMH>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 32 * BMH, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
     }
     if (lin + (int)gridDim.x < nwg) __syncthreads();   // slices are tile memory again for the next fill
     }   // tile loop
@@ -727,6 +734,28 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
     if ((p.tr_mode & 255) == 8) return smx_gemm_pp(p, stream);        // 256 x 256, persistent ping-pong
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
+    if (p.tr_mode == 9) {     // 64 x 128 tiles of the same kernel (gemm_bf16_dma_kernel<.., BMH = 1>): K-contiguous A, aligned classes
+        const bool flagged = (p.act & SMX_ACT_SAVE_GRAD) != 0;
+        const int epi = (p.atomic == 0 && smx_epi_views_aligned(p)) ? pp_epi_class(p) : -1;
+        if (p.a_rc || p.split_k != 1 || epi < 0 || epi == PP_EPI_F32) return SMX_EINVAL;
+        dim3 g9(((p.M + 63) / 64) * ((p.N + BN - 1) / BN), 1, p.nbatch);
+        if (g9.x > 1024) g9.x = 1024;
+        p.tr_mode = 1;
+#define TR9_GO(BR, E) hipLaunchKernelGGL((gemm_bf16_dma_kernel<false, BR, E, 1>), g9, dim3(256), STAGE_BYTES, stream, p)
+        if (!p.b_rc) {
+            if (epi == PP_EPI_LINEAR) TR9_GO(false, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACT && flagged) TR9_GO(false, 4);
+            else if (epi == PP_EPI_ACT) TR9_GO(false, PP_EPI_ACT);
+            else return SMX_EINVAL;
+        } else {
+            if (epi == PP_EPI_LINEAR) TR9_GO(true, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACTGRAD && flagged && !p.bias) TR9_GO(true, 5);
+            else if (epi == PP_EPI_ACTGRAD && !flagged) TR9_GO(true, PP_EPI_ACTGRAD);
+            else return SMX_EINVAL;
+        }
+#undef TR9_GO
+        SMX_CHECK_LAUNCH();
+    }
     if (p.tr_mode == 1 || p.tr_mode == 4) {   // LDS-DMA fills, 128x128 tile, 4 workgroups / CU
         const size_t ldsz = STAGE_BYTES;
         // specialised epilogue when the launch belongs to a class and every view allows 16-B accesses (SMX_TR1_EPI=0: off)

@@ -20,7 +20,7 @@ struct SmxGemmParams {
     int out_f32;            // C is fp32 regardless of input dtype
     int atomic;             // 0: C = .., 1: C += via fp32 atomics, 2: C += by plain read-modify-write (split_k == 1)
     int nbatch, split_k;    // split_k > 1 with atomic == 0: split s writes its partial to C + s * split_stride ("slabs")
-    int tr_mode;            // 1: 128x128 LDS-DMA kernel, 8: 256x256 ping-pong kernel (gemm_pp.hip), 2: register-staged + tr reads, 0: 16-bit LDS reads (debug)
+    int tr_mode;            // 1: 128x128 LDS-DMA kernel, 9: its 64x128 form, 8: 256x256 ping-pong kernel (gemm_pp.hip), 2: register-staged + tr reads, 0: 16-bit LDS reads (debug)
     float alpha;
     long long split_stride; // elements between split-K slabs (atomic == 0)
     float drop_p;           // dropout applied after the activation and before the residual add (0: off); in the

@@ -117,13 +117,34 @@ def _time_mode(p, dtype, mode, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+HALF_MODE = os.environ.get("SMX_GEMM_HALF", "auto")      # 64 x 128 tiles of the 128x128 kernel (tr_mode 9): auto | 0 | 1
+
+
+def _half_applicable(p, dtype):
+    """tr_mode 9 covers K-contiguous A operands, bf16 outputs of the aligned epilogue classes, no split-K; it is only worth
+    timing when the 128-row tiling leaves a good part of the 1024 resident workgroup slots empty."""
+    if HALF_MODE == "0" or dtype != L.BF16 or p.a_rc or p.split_k != 1 or p.out_f32 or p.atomic:
+        return False
+    if (p.N & 7) or ((p.c.ld | p.c.off | p.e.ld | p.e.off) & 7) or p.M < 128:
+        return False
+    tiles = ((p.M + 127) // 128) * ((p.N + 127) // 128) * max(p.nbatch, 1)
+    return tiles < 640
+
+
 def _choose_mode(p, dtype):
-    """-> tr_mode for this launch (1 or 8)."""
-    if not pp_allowed() or not _pp_applicable(p, dtype):
+    """-> tr_mode for this launch: 1 (128x128), 8 (ping-pong) or 9 (64x128)."""
+    cands = [1]
+    if pp_allowed() and _pp_applicable(p, dtype):
+        if PP_MODE == "1":
+            return 8
+        cands.append(8)
+    if _half_applicable(p, dtype):
+        if HALF_MODE == "1":
+            return 9
+        cands.append(9)
+    if len(cands) == 1:
         return 1
-    if PP_MODE == "1":
-        return 8
-    key = (p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
+    key = (tuple(cands), p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
            p.act, p.out_f32, p.atomic, p.drop_p > 0, p.a.rows_per_batch > 0, p.b.rows_per_batch > 0, p.c.rows_per_batch > 0)
     mode = _TUNED.get(key)
     if mode is None:
@@ -131,10 +152,15 @@ def _choose_mode(p, dtype):
         safe = p.atomic == 0 and p.resid != p.C and p.aux_in != p.C and p.A != p.C and p.B != p.C
         mode = 1
         if safe:
-            t1, t8 = _time_mode(p, dtype, 1), _time_mode(p, dtype, 8)
-            mode = 8 if t8 < 0.97 * t1 else 1
+            times = {}
+            for m in cands:
+                try:
+                    times[m] = _time_mode(p, dtype, m)
+                except RuntimeError:              # a class the variant is not instantiated for
+                    pass
+            mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else 1.03))      # ties go to the 128x128 kernel
             if TUNE_LOG is not None:
-                TUNE_LOG.append((key, t1, t8, mode))
+                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9)))
         _TUNED[key] = mode
     return mode
 

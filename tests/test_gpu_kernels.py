@@ -248,6 +248,48 @@ def test_saved_activation_derivative_matches_the_recomputed_one():
         ops.gemm(A, W, Y0, M, N, K, ops.BF16, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out=S0, resid=Y1, tr_mode=1)
 
 
+def test_half_height_tiles_of_the_128_kernel_are_bit_identical_to_it():
+    """tr_mode 9 (64 x 128 tiles: twice the workgroups for launches that leave most resident slots empty) runs the same
+    K order and the same epilogue arithmetic as tr_mode 1, so every instantiated class must agree bit for bit: forward
+    LINEAR (+bias, dropout, residual), ACT (+pre-activation copy), ACT with the saved derivative, data gradient LINEAR,
+    ACTGRAD and its saved-derivative form; ragged M; classes it is not built for are refused."""
+    import torch
+    from speechmix_amd import ops
+    from speechmix_amd.ops import ACT_GELU, view
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    for (M, N, K) in ((7968, 768, 3072), (1024, 768, 768), (1000, 200, 192), (130, 3072, 768)):
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        Wt = W.t().contiguous()                                  # [K, N]: rows-contiguous B operand of a data gradient
+        bias = torch.randn(N, device=dev) * 0.1
+        R = torch.randn(M, N, device=dev).bfloat16()
+        S = torch.randn(M, N, device=dev).bfloat16()
+        cases = {
+            "linear": dict(bias=bias, resid=R, drop=(0.1, 7)),
+            "act": dict(bias=bias, act=ACT_GELU, aux_out="aux", drop=(0.1, 8)),
+            "act_saved": dict(bias=bias, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out="aux", drop=(0.1, 9)),
+            "dgrad": dict(b_rc=True, bv=view(N)),
+            "dgrad_actgrad": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU, drop=(0.1, 10)),
+            "dgrad_saved": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU | ops.ACT_SAVE_GRAD),
+        }
+        for name, kw in cases.items():
+            outs = []
+            for mode in (1, 9):
+                Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                aux = torch.zeros_like(Y)
+                k2 = {k: (aux if isinstance(v, str) else v) for k, v in kw.items()}
+                ops.gemm(A, Wt if kw.get("b_rc") else W, Y, M, N, K, ops.BF16, tr_mode=mode, **k2)
+                outs.append((Y, aux))
+            assert torch.equal(outs[0][0], outs[1][0]), (name, M, N, K)
+            assert torch.equal(outs[0][1], outs[1][1]), (name, M, N, K)
+            assert outs[0][0].float().abs().max().item() > 0
+    Yf = torch.zeros(1024, 768, dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError):                            # fp32 outputs (split-K slabs) stay on the 128-row kernel
+        ops.gemm(torch.zeros(1024, 768, device=dev).bfloat16(), torch.zeros(768, 768, device=dev).bfloat16(), Yf, 1024, 768, 768,
+                 ops.BF16, out_f32=True, tr_mode=9)
+
+
 @pytest.mark.parametrize("V", [50265, 130, 64])
 def test_cross_entropy_two_pass_kernel_matches_torch(V):
     """loss (mean over valid tokens, ignore_index -100), first arg max and d loss / d logits of the vectorised two-pass kernel."""

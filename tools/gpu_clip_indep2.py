@@ -28,4 +28,4 @@ b = run(wave[:1].contiguous())
 for k in a:
     d = (a[k] - b[k]).abs()
     print(f"{k}: max diff {d.max().item():.3e} (scale {a[k].abs().max().item():.3e}), differing elements {int((d > 0).sum())} of {d.numel()}")
-print("tuning decisions:", [(k[:7], m) for k, t1, t8, m in ops.TUNE_LOG][:20])
+print("tuning decisions:", [(k[:7], m) for k, t1, t8, m, *_ in ops.TUNE_LOG][:20])
