@@ -48,6 +48,11 @@ int smx_gemm(const SmxGemmParams* p, int dtype, hipStream_t stream);
 /* second stage of a split-K forward / data-gradient GEMM: C = epilogue(sum_s slabs[s]); slabs: nsplit x [M, ldn] fp32 */
 int smx_gemm_splitk_epilogue(const SmxGemmParams* p, const float* slabs, int nsplit, long long stride, int ldn, hipStream_t stream);
 int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stride, float* dst, int accumulate, hipStream_t stream);
+/* Up to 4 weight-gradient GEMMs (a_rc = b_rc = 1, fp32 output: plain or split-K slabs, plain row views) in ONE persistent
+ * launch of the 256x256 kernel: the (K slice, tile) work lists of the problems are concatenated, so the weight gradients of
+ * one transformer layer (the autograd of the nn.Linear calls at TF:models/wav2vec2/modeling_wav2vec2.py:466-572) fill the
+ * chip with two K slices per output tile instead of seven each.  probs: `count` parameter blocks in host memory. */
+int smx_gemm_group(const SmxGemmParams* probs, int count, int dtype, hipStream_t stream);
 
 /* LayerNorm / RMSNorm (+ fused positional-table add, + fused activation) forward and backward.
  * TF:models/wav2vec2/modeling_wav2vec2.py:275-299, 429-434, 575-654; TF:models/bart/modeling_bart.py:507-549;

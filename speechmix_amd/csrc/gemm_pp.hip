@@ -68,6 +68,29 @@ __device__ __forceinline__ const SmxGemmParams& pp_kernarg() {
     asm volatile("" : "+s"(k));
     return *(const SmxGemmParams*)k;
 }
+// Grouped launches (smx_gemm_group): up to PP_MAXG independent problems of one (layout, epilogue class) share ONE launch;
+// their work items are concatenated (problem g owns items wstart[g] .. wstart[g+1]-1 of the launch).  A layer's four weight
+// gradients then fill the chip with TWO K slices per output tile instead of seven each, which cuts the slab traffic of the
+// split-K reduction 3.5x and four launches (+ their tails) to one.
+#define PP_MAXG 4
+struct SmxGemmGroup {
+    int count, W;
+    int wstart[PP_MAXG + 1];
+    int _pad;
+    SmxGemmParams prob[PP_MAXG];
+};
+template <bool GRP>
+__device__ __forceinline__ const SmxGemmParams& pp_kernarg_g(int g) {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    if constexpr (GRP) return ((const SmxGemmGroup*)k)->prob[g];
+    else return *(const SmxGemmParams*)k;
+}
+__device__ __forceinline__ const SmxGemmGroup& pp_group() {
+    auto k = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *(const SmxGemmGroup*)k;
+}
 
 // 4 B per lane: LDS[m0 + lane * 4] = mem[rsrc.base + voff]  (zeros beyond num_records)
 __device__ __forceinline__ void pp_dma4(pp_rsrc_t rsrc, unsigned voff, unsigned lds_wave_base) {
@@ -233,22 +256,36 @@ struct PPOperand {
 };
 
 // Issue side of the flat unit stream: runs six units ahead of the compute side over the same (item, K tile) sequence.
-template <bool A_RC, bool B_RC, bool BVIEW>
+template <bool A_RC, bool B_RC, bool BVIEW, bool GRP = false>
 struct PPIssue {
     PPOperand<A_RC, true, BVIEW && A_RC> a;    // BVIEW: the (RC, RC) instantiation whose operands go through batched views
     PPOperand<B_RC, false, BVIEW> b;
     PPDiv dv;
     int q, qstep;
     int kt, nk, k0, seq, wave_u, K;
+    int g;                  // GRP: problem of the item being issued
     unsigned lds0;          // LDS byte address of the stage buffers
     bool live;
 
     __device__ __forceinline__ void load_item(int tid) {
-        live = q < dv.W;
-        if (!live) return;
-        const SmxGemmParams& p = pp_kernarg();
+        if constexpr (GRP) {
+            live = q < pp_group().W;
+            if (!live) return;
+            while (q >= pp_group().wstart[g + 1]) ++g;          // items are handed out in increasing order
+        } else {
+            live = q < dv.W;
+            if (!live) return;
+        }
+        const SmxGemmParams& p = pp_kernarg_g<GRP>(g);
         PPItem it;
-        pp_decode(p, dv, q, it);
+        if constexpr (GRP) {
+            PPDiv d;
+            d.init(p, (p.M + PP_BM - 1) / PP_BM, (p.N + PP_BN - 1) / PP_BN);
+            pp_decode(p, d, q - pp_group().wstart[g], it);
+            K = p.K;
+        } else {
+            pp_decode(p, dv, q, it);
+        }
         k0 = it.ks0 * BK;
         nk = it.nk;                       // >= 1: the launcher rejects split counts that leave a slice empty
         kt = 0;
@@ -297,9 +334,9 @@ __device__ __forceinline__ bf16x8_t pp_bfrag(const char* unit, int r32, int j, i
     return f.v;
 }
 
-template <int PH, bool A_RC, bool B_RC, bool BVIEW, int LAB>
+template <int PH, bool A_RC, bool B_RC, bool BVIEW, int LAB, class ISSUE>
 __device__ __forceinline__ void pp_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4][2],
-                                         bf16x8_t (&fb0)[2][2], bf16x8_t (&fb1)[2][2], PPIssue<A_RC, B_RC, BVIEW>& is,
+                                         bf16x8_t (&fb0)[2][2], bf16x8_t (&fb1)[2][2], ISSUE& is,
                                          const char* cur, int tid, int lane, int wr, int wc, int wmode) {
     // LAB (ablation builds only): 1 no DMA, 2 no LDS reads, 4 no MFMA, 16 no epilogue, 64 fills re-read one K tile (L2-resident)
     // ---- load segment: register sub-tile reads + one unit of LDS-DMA, then the counted wait for the NEXT phase's unit
@@ -362,9 +399,10 @@ __device__ __forceinline__ void pp_phase(f32x4_t (&acc)[8][4], bf16x8_t (&fa)[4]
 }
 
 // acc[rh*4+a][2 ch + j][r]: row mw0 + rh*64 + a*16 + (lane & 15), column nw0 + ch*32 + 8 (lane >> 4) + 4 j + r
+template <bool GRP = false>
 __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[8][4], int mw0, int nw0, long long zc, long long zbias,
-                                            long long ze, int lane) {
-    const SmxGemmParams& p = pp_kernarg();
+                                            long long ze, int lane, int gi = 0) {
+    const SmxGemmParams& p = pp_kernarg_g<GRP>(gi);
     const int i16 = lane & 15, g = lane >> 4;
     float bs[2][8];
 #pragma unroll
@@ -421,10 +459,10 @@ __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
     return !(m & 7) && !(p.N & 7);
 }
 
-template <int EPI>
+template <int EPI, bool GRP = false>
 __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, int nw0, int n0, const char* bias_lds,
-                                                 long long zc, long long ze, int lane) {
-    const SmxGemmParams& p = pp_kernarg();
+                                                 long long zc, long long ze, int lane, int gi = 0) {
+    const SmxGemmParams& p = pp_kernarg_g<GRP>(gi);
     const int i16 = lane & 15, g = lane >> 4;
     const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
     // bias: the item's 256-column slice was put into LDS by an LDS-DMA issued when the item started (zeros beyond N)
@@ -560,16 +598,20 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
     }
 }
 
-template <bool A_RC, bool B_RC, int EPI, int LAB = 0, bool BVIEW = false>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
+template <bool A_RC, bool B_RC, int EPI, int LAB, bool BVIEW, bool GRP, class KARG>
+__device__ __forceinline__ void pp_kernel_body(const KARG& karg) {
+    static_assert(!GRP || !BVIEW, "grouped launches: plain operand views");
+    const SmxGemmParams& p = pp_kernarg_g<GRP>(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
     const int ntm = (p.M + PP_BM - 1) / PP_BM, ntn = (p.N + PP_BN - 1) / PP_BN;
-    const int W = ntm * ntn * p.nbatch * p.split_k;
+    int W = ntm * ntn * p.nbatch * p.split_k;
+    if constexpr (GRP) W = pp_group().W;
 
-    PPIssue<A_RC, B_RC, BVIEW> is;
+    PPIssue<A_RC, B_RC, BVIEW, GRP> is;
     is.dv.init(p, ntm, ntn);
+    is.g = 0;
     is.q = blockIdx.x; is.qstep = gridDim.x;
     is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
     is.wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -601,17 +643,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
     int seq = 0, items = 0;
     bool drained = false;
     // the launcher sets bit 7 of tr_mode when the parameters fit this instantiation's epilogue class
-    const bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
+    bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
+    int gc = 0;                 // GRP: problem of the item being computed
     for (int q = blockIdx.x; q < W; q += gridDim.x) {
         PPItem it;
-        pp_decode(pp_kernarg(), is.dv, q, it);
+        if constexpr (GRP) {
+            while (q >= pp_group().wstart[gc + 1]) ++gc;
+            const SmxGemmParams& pg = pp_kernarg_g<true>(gc);
+            PPDiv d;
+            d.init(pg, (pg.M + PP_BM - 1) / PP_BM, (pg.N + PP_BN - 1) / PP_BN);
+            pp_decode(pg, d, q - pp_group().wstart[gc], it);
+            fast_epi = (pg.tr_mode & 128) && pp_views_aligned(pg);
+        } else {
+            pp_decode(pp_kernarg(), is.dv, q, it);
+        }
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         ++items;
         if (fast_epi && wr == 0) {          // bias slice of this item -> LDS, behind everything already in flight (the last
-            const SmxGemmParams& pk = pp_kernarg();      // phase's drain retires it; an extra older operation only makes
+            const SmxGemmParams& pk = pp_kernarg_g<GRP>(gc);      // phase's drain retires it; an extra older operation only makes
             if (pk.bias) {                                // the counted waits stricter)
                 pp_rsrc_t br = pp_make_rsrc(pk.bias + it.zbias + it.n0);
                 br[2] = max(pk.N - it.n0, 0) * 4;
@@ -632,15 +684,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
         if constexpr ((LAB & 16) != 0) {
             float sink = 0.f;
             for (int a = 0; a < 8; ++a) for (int j = 0; j < 4; ++j) sink += acc[a][j][0] + acc[a][j][1] + acc[a][j][2] + acc[a][j][3];
-            if (sink == 1234.5f) reinterpret_cast<float*>(p.C)[tid] = sink;
+            if (sink == 1234.5f) reinterpret_cast<float*>(pp_kernarg_g<GRP>(0).C)[tid] = sink;
         } else if (fast_epi) {
-            pp_epilogue_fast<EPI>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
-                                  it.ze, lane);
+            pp_epilogue_fast<EPI, GRP>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
+                                       it.ze, lane, gc);
         } else {
-            pp_epilogue(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane);
+            pp_epilogue<GRP>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+}
+
+template <bool A_RC, bool B_RC, int EPI, int LAB = 0, bool BVIEW = false>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(SmxGemmParams p) {
+    pp_kernel_body<A_RC, B_RC, EPI, LAB, BVIEW, false>(p);
+}
+// grouped form (smx_gemm_group): the same body over the concatenated work lists of up to PP_MAXG problems
+template <bool A_RC, bool B_RC, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_group_kernel(SmxGemmGroup grp) {
+    pp_kernel_body<A_RC, B_RC, EPI, 0, false, true>(grp);
 }
 
 template <bool A_RC, bool B_RC, int EPI, bool BVIEW = false>
@@ -720,3 +782,49 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
     PP_GO(true, false, PP_EPI_F32)
 #undef PP_GO
 }
+
+// Up to PP_MAXG weight-gradient problems (rows-contiguous operands, fp32 slab or plain fp32 output, plain views) in ONE
+// persistent launch: their (K slice, tile) work lists are concatenated.  Declared in include/speechmix_hip.h.
+extern "C" int smx_gemm_group(const SmxGemmParams* probs, int count, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!probs || count < 1 || count > PP_MAXG || dtype != SMX_BF16) return SMX_EINVAL;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+        ncu &= ~7;
+    }
+    SmxGemmGroup grp = {};
+    grp.count = count;
+    long long W = 0;
+    for (int g = 0; g < count; ++g) {
+        SmxGemmParams p = probs[g];
+        if (p.nbatch < 1) p.nbatch = 1;
+        if (p.split_k < 1) p.split_k = 1;
+        if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nbatch != 1 || !p.a_rc || !p.b_rc || !p.out_f32 || p.atomic == 1 ||
+            (p.split_k > 1 && (p.atomic != 0 || p.split_stride <= 0)) || p.a.rows_per_batch > 0 || p.b.rows_per_batch > 0 ||
+            p.c.rows_per_batch > 0 || pp_epi_class(p) != PP_EPI_F32 || (p.act & SMX_ACT_SAVE_GRAD))
+            return SMX_EINVAL;
+        const int kst = (p.K + BK - 1) / BK, per = (kst + p.split_k - 1) / p.split_k;
+        const long long w = (long long)((p.M + PP_BM - 1) / PP_BM) * ((p.N + PP_BN - 1) / PP_BN) * p.split_k;
+        if (w >= (1 << 22) || p.M >= (1 << 22) || p.N >= (1 << 22) || p.K >= (1 << 22) || (p.split_k - 1) * per >= kst) return SMX_EINVAL;
+        p.tr_mode = 8 | 128;                 // the class-specialised epilogue (taken when the views are 16-B aligned)
+        grp.prob[g] = p;
+        grp.wstart[g] = (int)W;
+        W += w;
+    }
+    if (W >= (1 << 22)) return SMX_EINVAL;
+    for (int g = count; g <= PP_MAXG; ++g) grp.wstart[g] = (int)W;
+    grp.W = (int)W;
+    dim3 grid((unsigned)(W < ncu ? W : ncu));
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_group_kernel<true, true, PP_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_pp_group_kernel<true, true, PP_EPI_F32>), grid, dim3(512), PP_LDS_BYTES, stream, grp);
+    SMX_CHECK_LAUNCH();
+}
+

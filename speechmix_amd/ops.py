@@ -707,6 +707,25 @@ def _reduce_slabs(slabs, nsplit, n, stride, dst, accumulate):
                                      C.c_void_p(_ptr(dst)), int(accumulate), _stream()), "smx_reduce_slabs")
 
 
+def gemm_group(problems, dtype):
+    """ONE persistent launch of the 256x256 kernel over up to 4 weight-gradient problems (smx_gemm_group).  problems: list of
+    (a, b, c, M, N, K, kw) with the arguments of `gemm` (a_rc = b_rc = True, out_f32, plain views)."""
+    arr = (L.GemmParams * len(problems))()
+    flops = 0.0
+    for i, (a, b, c, M, N, K, kw) in enumerate(problems):
+        arr[i] = _gemm_params(a, b, c, M, N, K, **kw)
+        flops += 2.0 * M * N * K
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = prof.events()
+        e0.record()
+    L.check(L.lib().smx_gemm_group(arr, len(problems), dtype, _stream()), "smx_gemm_group")
+    if prof is not None:
+        e1.record()
+        a, b, c, M, N, K, kw = problems[0]
+        prof.add((1, 1, 8), e0, e1, flops, ("group", len(problems), K, 1, kw.get("split_k", 1)))
+
+
 def softmax_rows(x, R, Cn):
     L.check(L.lib().smx_softmax_rows(C.c_void_p(_ptr(x)), R, Cn, _stream()), "smx_softmax_rows")
 

@@ -248,6 +248,43 @@ def test_saved_activation_derivative_matches_the_recomputed_one():
         ops.gemm(A, W, Y0, M, N, K, ops.BF16, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out=S0, resid=Y1, tr_mode=1)
 
 
+def test_grouped_weight_gradient_launch_equals_the_separate_launches():
+    """smx_gemm_group: four weight-gradient problems of different output shapes (one with a ragged tile edge) and split
+    counts in one launch; every slab must be bit-identical to the slab the single-problem launch writes (same kernel body,
+    same K slices), and the plain (split 1) fp32 form must work inside a group too."""
+    import torch
+    from speechmix_amd import ops
+    from speechmix_amd.ops import view
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    Kred = 4000
+    shapes = [(768, 3072, 2), (3072, 768, 2), (2304, 768, 3), (200, 776, 1)]
+    probs, refs, outs = [], [], []
+    for (No, Ko, sp) in shapes:
+        dy = torch.randn(Kred, No, device=dev).bfloat16()
+        x = torch.randn(Kred, Ko, device=dev).bfloat16()
+        n = No * Ko
+        ref = torch.zeros(sp * n, dtype=torch.float32, device=dev)
+        out = torch.zeros(sp * n, dtype=torch.float32, device=dev)
+        kw = dict(a_rc=True, b_rc=True, av=view(No), bv=view(Ko), out_f32=True, atomic=0, alpha=0.5)
+        if sp > 1:
+            kw.update(split_k=sp, split_stride=n)
+        ops.gemm(dy, x, ref, No, Ko, Kred, ops.BF16, tr_mode=8, **kw)
+        probs.append((dy, x, out, No, Ko, Kred, kw))
+        refs.append(ref); outs.append(out)
+    ops.gemm_group(probs, ops.BF16)
+    torch.cuda.synchronize()
+    for (No, Ko, sp), ref, out in zip(shapes, refs, outs):
+        assert ref.abs().max().item() > 0
+        assert torch.equal(ref, out), (No, Ko, sp)
+    fp = (probs[0][0].float().t() @ probs[0][1].float()) * 0.5
+    got = outs[0].view(2, 768, 3072).sum(0)
+    assert (got - fp).abs().max().item() <= 2e-3 * fp.abs().max().item()
+    with pytest.raises(RuntimeError):                                  # bf16 outputs are not a group class
+        a, b, c, M, N, K, kw = probs[0]
+        ops.gemm_group([(a, b, torch.zeros(M, N, dtype=torch.bfloat16, device=dev), M, N, K, dict(a_rc=True, b_rc=True, av=view(M), bv=view(N)))], ops.BF16)
+
+
 def test_half_height_tiles_of_the_128_kernel_are_bit_identical_to_it():
     """tr_mode 9 (64 x 128 tiles: twice the workgroups for launches that leave most resident slots empty) runs the same
     K order and the same epilogue arithmetic as tr_mode 1, so every instantiated class must agree bit for bit: forward
