@@ -48,6 +48,9 @@ int smx_gemm(const SmxGemmParams* p, int dtype, hipStream_t stream);
 /* second stage of a split-K forward / data-gradient GEMM: C = epilogue(sum_s slabs[s]); slabs: nsplit x [M, ldn] fp32 */
 int smx_gemm_splitk_epilogue(const SmxGemmParams* p, const float* slabs, int nsplit, long long stride, int ldn, hipStream_t stream);
 int smx_reduce_slabs(const float* slabs, int nsplit, long long n, long long stride, float* dst, int accumulate, hipStream_t stream);
+/* reduce_slabs for up to 8 (slabs, destination) pairs in one launch; arrays in host memory, slab stride = n[e] */
+int smx_reduce_slabs_many(const float* const* slabs, float* const* dst, const long long* n, const int* nsplit, int count,
+                          int accumulate, hipStream_t stream);
 /* Up to 4 weight-gradient GEMMs (a_rc = b_rc = 1, fp32 output: plain or split-K slabs, plain row views) in ONE persistent
  * launch of the 256x256 kernel: the (K slice, tile) work lists of the problems are concatenated, so the weight gradients of
  * one transformer layer (the autograd of the nn.Linear calls at TF:models/wav2vec2/modeling_wav2vec2.py:466-572) fill the

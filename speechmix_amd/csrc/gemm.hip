@@ -677,6 +677,50 @@ extern "C" int smx_reduce_slabs(const float* slabs, int nsplit, long long n, lon
     SMX_CHECK_LAUNCH();
 }
 
+// reduce_slabs for several (slabs, destination) pairs in one launch (the second stage of a grouped weight-gradient launch)
+#define SMX_REDUCE_MAX 8
+struct SmxReduceTable {
+    const float* slabs[SMX_REDUCE_MAX];
+    float* dst[SMX_REDUCE_MAX];
+    long long n[SMX_REDUCE_MAX];             // elements per slab (= slab stride), % 4 == 0
+    int nsplit[SMX_REDUCE_MAX];
+    int count, accumulate;
+};
+__global__ void reduce_slabs_many_kernel(SmxReduceTable t) {
+    const int e = blockIdx.y;
+    const float* __restrict__ slabs = t.slabs[e];
+    float* __restrict__ dst = t.dst[e];
+    const long long n = t.n[e];
+    const int nsplit = t.nsplit[e];
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (; i + 4 <= n; i += step) {
+        float4 a = t.accumulate ? *reinterpret_cast<const float4*>(dst + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < nsplit; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + s * n + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + i) = a;
+    }
+}
+extern "C" int smx_reduce_slabs_many(const float* const* slabs, float* const* dst, const long long* n, const int* nsplit, int count,
+                                     int accumulate, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!slabs || !dst || !n || !nsplit || count < 1 || count > SMX_REDUCE_MAX) return SMX_EINVAL;
+    SmxReduceTable t = {};
+    long long nmax = 0;
+    for (int e = 0; e < count; ++e) {
+        if (!slabs[e] || !dst[e] || n[e] <= 0 || (n[e] & 3) || nsplit[e] < 1) return SMX_EINVAL;
+        t.slabs[e] = slabs[e]; t.dst[e] = dst[e]; t.n[e] = n[e]; t.nsplit[e] = nsplit[e];
+        nmax = n[e] > nmax ? n[e] : nmax;
+    }
+    t.count = count; t.accumulate = accumulate;
+    long long blocks = (nmax / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(reduce_slabs_many_kernel, dim3((unsigned)blocks, count), dim3(256), 0, stream, t);
+    SMX_CHECK_LAUNCH();
+}
+
 // Second stage of a split-K forward / data-gradient GEMM (outputs with fewer tiles than CUs: the decoder, the LM head):
 // C = epilogue(sum_s slabs[s]) with the full epilogue of SmxGemmParams (bias, activation or activation gradient,
 // dropout, residual, aux_out, bf16 / fp32 / accumulate).  slabs: nsplit x [M, ldn] fp32, rows padded to ldn % 8 == 0.

@@ -318,8 +318,8 @@ class Engine:
                 kw.update(atomic=2)
             probs.append((dy, x, dst, N, K, M, kw))
         ops.gemm_group(probs, self.dt)
-        for dst, sp, n, gw in outs:
-            ops.reduce_slabs(dst, sp, n, n, gw, accumulate=True)
+        if outs:
+            ops.reduce_slabs_many([(dst, sp, n, gw) for dst, sp, n, gw in outs], accumulate=True)
 
     def ln_fwd(self, x, wname, bname, M, D, eps, rms=False, act=ACT_NONE, pos=None, pos_period=0, pos_offset=0,
                want_sum=False, drop=None):

@@ -726,6 +726,17 @@ def gemm_group(problems, dtype):
         prof.add((1, 1, 8), e0, e1, flops, ("group", len(problems), K, 1, kw.get("split_k", 1)))
 
 
+def reduce_slabs_many(items, accumulate=True):
+    """items: [(slabs, nsplit, n, dst)] with slab stride n - one launch for all of them (smx_reduce_slabs_many)."""
+    k = len(items)
+    sl = (C.c_void_p * k)(*[_ptr(it[0]) for it in items])
+    ds = (C.c_void_p * k)(*[_ptr(it[3]) for it in items])
+    ns = (C.c_longlong * k)(*[it[2] for it in items])
+    sp = (C.c_int * k)(*[it[1] for it in items])
+    with _Span("reduce_slabs", 4.0 * sum(it[2] * (it[1] + (2 if accumulate else 1)) for it in items)):
+        L.check(L.lib().smx_reduce_slabs_many(sl, ds, ns, sp, k, int(accumulate), _stream()), "smx_reduce_slabs_many")
+
+
 def softmax_rows(x, R, Cn):
     L.check(L.lib().smx_softmax_rows(C.c_void_p(_ptr(x)), R, Cn, _stream()), "smx_softmax_rows")
 

@@ -280,6 +280,11 @@ def test_grouped_weight_gradient_launch_equals_the_separate_launches():
     fp = (probs[0][0].float().t() @ probs[0][1].float()) * 0.5
     got = outs[0].view(2, 768, 3072).sum(0)
     assert (got - fp).abs().max().item() <= 2e-3 * fp.abs().max().item()
+    # second stage in one launch: every destination += the sum of its slabs
+    dsts = [torch.ones(No * Ko, dtype=torch.float32, device=dev) for (No, Ko, sp) in shapes[:3]]
+    ops.reduce_slabs_many([(o, sp, No * Ko, d) for (No, Ko, sp), o, d in zip(shapes[:3], outs[:3], dsts)], accumulate=True)
+    for (No, Ko, sp), o, d in zip(shapes[:3], outs[:3], dsts):
+        assert torch.equal(d, 1.0 + o.view(sp, -1).sum(0)) or (d - (1.0 + o.view(sp, -1).sum(0))).abs().max().item() <= 1e-5 * d.abs().max().item()
     with pytest.raises(RuntimeError):                                  # bf16 outputs are not a group class
         a, b, c, M, N, K, kw = probs[0]
         ops.gemm_group([(a, b, torch.zeros(M, N, dtype=torch.bfloat16, device=dev), M, N, K, dict(a_rc=True, b_rc=True, av=view(M), bv=view(N)))], ops.BF16)
