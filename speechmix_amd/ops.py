@@ -217,7 +217,8 @@ class GemmProfile:
     def name(key):
         a, b, mode = key
         kern = "gemm_bf16_pp_kernel" if mode == 8 else "gemm_bf16_dma_kernel"
-        return f"{kern}<{str(bool(a)).lower()},{str(bool(b)).lower()}> ({GemmProfile._ROLE[(a, b)]})"
+        tile = ", 64x128 tiles" if mode == 9 else ""
+        return f"{kern}<{str(bool(a)).lower()},{str(bool(b)).lower()}> ({GemmProfile._ROLE[(a, b)]}{tile})"
 
     def __init__(self):
         self.pool, self.used, self.recs = [], 0, []
