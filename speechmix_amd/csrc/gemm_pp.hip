@@ -735,8 +735,11 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
     // rows-contiguous operands through a batched view: instantiated for the (RC, RC) layout (conv weight gradients) and for
     // the B operand of the (KC, RC) layout (conv data gradients: the tap-major packed weight read tap by tap)
     if (p.a_rc && !p.b_rc && p.a.rows_per_batch > 0) return SMX_EINVAL;
-    dim3 grid((unsigned)(W < ncu ? W : ncu));
-    const int lab = p.tr_mode >> 8;
+    // bits 16.. of tr_mode: cap of the persistent grid (the caller keeps CUs free for a kernel running beside this one)
+    const int cap = (p.tr_mode >> 16) & 0xfff;
+    const int wgs = cap > 0 && cap < ncu ? cap : ncu;
+    dim3 grid((unsigned)(W < wgs ? W : wgs));
+    const int lab = (p.tr_mode >> 8) & 0xff;
     const int epi = pp_epi_class(p);
     p.tr_mode = 8;
 #ifdef SMX_PP_LAB
@@ -818,7 +821,9 @@ extern "C" int smx_gemm_group(const SmxGemmParams* probs, int count, int dtype, 
     if (W >= (1 << 22)) return SMX_EINVAL;
     for (int g = count; g <= PP_MAXG; ++g) grp.wstart[g] = (int)W;
     grp.W = (int)W;
-    dim3 grid((unsigned)(W < ncu ? W : ncu));
+    const int cap = (probs[0].tr_mode >> 16) & 0xfff;          // as in smx_gemm_pp
+    const int wgs = cap > 0 && cap < ncu ? cap : ncu;
+    dim3 grid((unsigned)(W < wgs ? W : wgs));
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_group_kernel<true, true, PP_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);

@@ -214,7 +214,7 @@ class Engine:
 
         pick = 0
         if len(cands) > 1:
-            key = ("wgrad", No, Ko, Kred, av.rows_per_batch > 0, bv.rows_per_batch > 0, tuple(sorted(kw)))
+            key = ("wgrad", ops.pp_cus(), No, Ko, Kred, av.rows_per_batch > 0, bv.rows_per_batch > 0, tuple(sorted(kw)))
             pick = self._wgrad_pick.get(key)
             if pick is None:
                 pick = 0
@@ -297,7 +297,7 @@ class Engine:
             return
         tiles = sum(((N + 255) // 256) * ((K + 255) // 256) for _, _, _, N, K, _, _, _, _ in grp)
         ksteps = min((M + 63) // 64 for _, _, _, _, _, M, _, _, _ in grp)
-        want = max(1, min(256 // max(tiles, 1), ksteps // 4))
+        want = max(1, min((ops.pp_cus() or 256) // max(tiles, 1), ksteps // 4))
         total = sum(N * K for _, _, _, N, K, _, _, _, _ in grp)
         probs, outs = [], []
         slabs = self.workspace("wg_group_" + self._slab_key(), (want + 1) * total, torch.float32) if want > 1 else None

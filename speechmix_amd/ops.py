@@ -67,11 +67,21 @@ _TUNED = {}
 # The ping-pong kernel needs a whole CU per workgroup (160 KB of LDS, the full register file).  A kernel running beside it
 # - RCCL's all-reduce of the gradient buckets on the side stream during backward - takes CUs away, and the displaced
 # workgroups then run as a second round (up to 2x the launch time), where the 4-workgroup/CU kernel only loses a quarter of
-# those CUs.  StepRunner clears this flag when gradients are all-reduced concurrently (world size > 1); forward launches
-# (nothing runs beside them) keep the choice.  SMX_GEMM_PP=1 overrides; SMX_PP_BACKWARD=0 clears the flag on a single GPU
-# (what the policy costs there: DESIGN.md section 5).
+# those CUs.  When gradients are all-reduced concurrently (world size > 1, StepRunner sets PP_BACKWARD_CUS) the ping-pong
+# launches of backward therefore leave CUs free for RCCL: their persistent grid and their K-slice counts are sized for
+# PP_BACKWARD_CUS workgroups (216: what an encoder layer's grouped weight-gradient launch uses anyway), so they finish in
+# one round as long as RCCL holds no more than 256 - 216 = 40 CUs; forward launches (nothing runs beside them) use every CU.
+# SMX_PP_BACKWARD=0 takes the ping-pong kernel out of backward altogether (the round-1 policy; cost on one GPU: DESIGN.md
+# section 5), SMX_PP_BACKWARD_CUS=n forces the reserve on a single GPU, SMX_GEMM_PP=1 overrides both.
 PP_CONCURRENT_BACKWARD_OK = os.environ.get("SMX_PP_BACKWARD", "1") != "0"
+PP_BACKWARD_CUS = int(os.environ.get("SMX_PP_BACKWARD_CUS", "0"))      # 0: all CUs
+PP_RESERVED_DEFAULT = 216
 IN_BACKWARD = False
+
+
+def pp_cus():
+    """Workgroups a ping-pong launch may occupy right now (0: every CU)."""
+    return PP_BACKWARD_CUS if (IN_BACKWARD and PP_BACKWARD_CUS > 0) else 0
 
 
 def pp_allowed():
@@ -101,6 +111,8 @@ def _pp_applicable(p, dtype):
 
 
 def _launch(p, dtype):
+    if (p.tr_mode & 255) == 8 and pp_cus():
+        p.tr_mode = (p.tr_mode & 0xffff) | (pp_cus() << 16)          # persistent grid cap (gemm_pp.hip)
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
 
 
@@ -144,7 +156,7 @@ def _choose_mode(p, dtype):
         cands.append(9)
     if len(cands) == 1:
         return 1
-    key = (tuple(cands), p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
+    key = (tuple(cands), pp_cus(), p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
            p.act, p.out_f32, p.atomic, p.drop_p > 0, p.a.rows_per_batch > 0, p.b.rows_per_batch > 0, p.c.rows_per_batch > 0)
     mode = _TUNED.get(key)
     if mode is None:
@@ -187,10 +199,11 @@ def gemm(a, b, c, M, N, K, dtype, **kw):
 
 
 def pp_split(Mo, No, Kred):
-    """K-slice count for a weight-gradient GEMM on the ping-pong kernel: one round of 256x256 work items over the CUs."""
+    """K-slice count for a weight-gradient GEMM on the ping-pong kernel: one round of 256x256 work items over the CUs
+    (over the CUs backward may use when RCCL runs beside it: pp_cus)."""
     tiles = ((Mo + 255) // 256) * ((No + 255) // 256)
     ksteps = (Kred + 63) // 64
-    want = max(1, min(256 // max(tiles, 1), ksteps // 4))
+    want = max(1, min((pp_cus() or 256) // max(tiles, 1), ksteps // 4))
     per = (ksteps + want - 1) // want
     return (ksteps + per - 1) // per
 
@@ -720,6 +733,8 @@ def gemm_group(problems, dtype):
     if prof is not None:
         e0, e1 = prof.events()
         e0.record()
+    if pp_cus():
+        arr[0].tr_mode = 8 | (pp_cus() << 16)
     L.check(L.lib().smx_gemm_group(arr, len(problems), dtype, _stream()), "smx_gemm_group")
     if prof is not None:
         e1.record()

@@ -89,7 +89,9 @@ class StepRunner:
         self._force_comm = force_comm
         self._refresh_trainable()
         if self.world > 1 or force_comm:
-            ops.PP_CONCURRENT_BACKWARD_OK = False   # RCCL runs beside backward: one-workgroup-per-CU kernels would be displaced
+            # RCCL runs beside backward: one-workgroup-per-CU kernels leave it CUs (ops.PP_BACKWARD_CUS)
+            if ops.PP_BACKWARD_CUS == 0:
+                ops.PP_BACKWARD_CUS = ops.PP_RESERVED_DEFAULT
         if self.world > 1 and sync_params:
             dist.broadcast(self.store.master, src=0)
         self.store.external_updates = False          # this runner keeps the bf16 compute copies fresh itself
