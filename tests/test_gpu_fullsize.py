@@ -78,6 +78,28 @@ def test_full_size_gradient_is_the_mean_of_its_half_batch_gradients(full):
     assert rel < 2e-2 and cos > 0.9995, (rel, cos)
 
 
+def test_full_size_gradient_does_not_depend_on_the_cu_reserve_for_rccl(full):
+    """With more than one rank the ping-pong launches of backward are sized for 216 workgroups (ops.PP_BACKWARD_CUS: the CUs left
+    to RCCL's kernels).  That changes persistent grids and K-slice counts, i.e. only the fp32 summation order of the weight
+    gradients: the same batch must give the same gradient with and without the reserve."""
+    from speechmix_amd import ops
+    from speechmix_amd.trainer import StepRunner
+    model, wave, labels = full
+    runner = StepRunner(model, lr=0.0, optimizer="sgd", max_grad_norm=0.0)
+    runner.step(wave, labels)
+    g0 = model.store.grad.clone()
+    old = ops.PP_BACKWARD_CUS
+    try:
+        ops.PP_BACKWARD_CUS = ops.PP_RESERVED_DEFAULT
+        runner.step(wave, labels)
+    finally:
+        ops.PP_BACKWARD_CUS = old
+    g1 = model.store.grad
+    assert torch.isfinite(g1).all()
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    assert rel < 1e-4, rel
+
+
 def test_full_size_training_steps_reduce_the_loss(full):
     from speechmix_amd.trainer import StepRunner
     model, wave, labels = full
