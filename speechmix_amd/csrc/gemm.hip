@@ -464,8 +464,10 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
     static_assert(BMH == 2 || !A_RC, "64-row tiles: K-contiguous A only");
     constexpr int TBM = 64 * BMH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.drop_seed == 0xdead0001u) return;      // LAB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SMX_PP_LAB
+    if (p.drop_seed == 0xdead0001u) return;      // ablation builds (tools/gpu_small_gemm.py): launch cost only
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: scalar registers)
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + TBM - 1) / TBM;
     const int nwg = ntn * ntm;
@@ -525,10 +527,16 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
 
     char* tA = smem;
     char* tB = smem + 16384;
+    // Waves whose whole sub-tile lies outside the output (edge tiles; the positional conv's 48-column groups use one of a
+    // tile's two wave columns) skip their fragment reads and MFMAs - the other workgroups of the CU use the idle pipes.
+    // (Finer, per-16-block predication made hipcc keep two copies of the accumulators: 220 spilled registers; skipping the
+    // fills of rows nobody reads put eight scalar branches into every K step and cost more than the fills.)
+    const bool wave_on = m0 + wm * 32 * BMH < p.M && n0 + wn * 64 < p.N;
     for (int ks = ks0; ks < ks1; ++ks) {
         la.issue(tA, p.a, m0, p.M, ks * BK, p.K, tid);
         lb.issue(tB, p.b, n0, p.N, ks * BK, p.K, tid);
         __syncthreads();                 // (the compiler drains the LDS-DMA queue before the barrier)
+        if (wave_on) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t fa[2 * BMH], fb[4];
@@ -542,9 +550,12 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+        }
         __syncthreads();                 // everyone is done reading before the next fill overwrites the tile
     }
-    if (p.drop_seed == 0xdead0002u) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[tid] = acc[1][1][1] + acc[2 * BMH - 1][2][2] + acc[2 * BMH - 1][3][3]; return; }   // LAB
+#ifdef SMX_PP_LAB
+    if (p.drop_seed == 0xdead0002u) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[tid] = acc[1][1][1] + acc[2 * BMH - 1][2][2] + acc[2 * BMH - 1][3][3]; return; }   // ablation builds: no epilogue
+#endif
     // the K loop ended on a barrier: the tile buffers are free, each wave transposes through its own 8-KB slice.
     // The lane id and the parameter block are re-read behind an opaque asm: everything the epilogue derives from them
     // (LDS addresses, row offsets, flags) is then computed HERE instead of being hoisted above the K loop, where it would
@@ -557,7 +568,9 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
         auto ka = __builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
         const SmxGemmParams& pe = *(const SmxGemmParams*)ka;
-        if constexpr (EPI >= 0)
+        if (!wave_on) {
+            // nothing of this wave's sub-tile lies inside the output
+        } else if constexpr (EPI >= 0)
             epilogue_staged_fast<EPI, (EPI == 6 && !A_RC && B_RC) ? 1 : 0, BMH>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 32 * BMH, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
         else
             epilogue_staged<BMH>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 32 * BMH, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
