@@ -68,6 +68,10 @@ typedef struct SmxNormBwdParams {
     const void *dy, *x, *dres; void* dx; const float *gamma, *beta, *mean, *rstd; float *dgamma, *dbeta, *dpos, *partials;
     int M, D, pos_period, pos_offset, rms, act; float drop_p; unsigned drop_seed;
     int defer_fold;   /* 1: leave the gamma/beta partial rows (smx_norm_bwd_partial_rows(M) x [2][D] floats) in `partials` for smx_fold_many */
+    /* optional (defer_fold == 1, no activation): dx_drop = dx * dropout mask (drop2_p, drop2_seed) of the Linear whose dropped output
+     * fed this norm (post-LN out_proj / fc2, TF:models/bart/modeling_bart.py:305-322) and its column sums - that Linear's bias
+     * gradient - as a third partial row per block: partials is then rows x [3][D] */
+    void* dx_drop; float drop2_p; unsigned drop2_seed;
 } SmxNormBwdParams;
 int smx_norm_fwd(const SmxNormParams* p, int dtype, hipStream_t stream);
 int smx_norm_bwd(const SmxNormBwdParams* p, int dtype, hipStream_t stream);

@@ -63,7 +63,8 @@ class NormBwdParams(C.Structure):
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dpos", C.c_void_p), ("partials", C.c_void_p),
                 ("M", C.c_int), ("D", C.c_int), ("pos_period", C.c_int), ("pos_offset", C.c_int),
-                ("rms", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint), ("defer_fold", C.c_int)]
+                ("rms", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint), ("defer_fold", C.c_int),
+                ("dx_drop", C.c_void_p), ("drop2_p", C.c_float), ("drop2_seed", C.c_uint)]
 
 
 FOLD_MAX = 48

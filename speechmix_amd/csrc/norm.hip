@@ -120,6 +120,12 @@ struct SmxNormBwdParams {
     unsigned drop_seed;
     int defer_fold;       // 1: leave the gamma / beta partial rows in `partials` (smx_norm_bwd_partial_rows(M) rows of
                           // [2][D] floats); the caller reduces them into dgamma / dbeta later (smx_fold_many)
+    // Optional third output (fused kernel, defer_fold == 1, no activation): dx_drop = dx * mask(drop2) - the gradient that
+    // enters a Linear whose dropped output fed this norm's input (post-LN layers: out_proj / fc2) - and its column sums
+    // (that Linear's bias gradient) as a THIRD partial row per block: `partials` is then [rows][3][D].
+    void* dx_drop;
+    float drop2_p;
+    unsigned drop2_seed;
 };
 
 // Backward is two kernels: (1) dx, one wave per row at full occupancy (like the forward); (2) the gamma/beta
@@ -274,6 +280,14 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
     const int row0 = (blockIdx.x * 4 + w) * LN_PR;
     const float invD = 1.0f / (float)p.D;
     float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
+    float dc[ACT ? 1 : LN_NCH][8];                 // column sums of the masked dx (third partial row)
+    const bool third = !ACT && p.dx_drop != nullptr;
+    const unsigned th2 = smx_thresh24(p.drop2_p);
+    const float inv2 = 1.0f / (1.0f - p.drop2_p);
+#pragma unroll
+    for (int j = 0; j < (ACT ? 1 : LN_NCH); ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dc[j][e] = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_NCH; ++j) {
         const int c = (lane + 64 * j) * 8;
@@ -346,6 +360,19 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
                         if (dres) o[e] += rr[e];
                     }
                     store8(dx + c, o);
+                    if constexpr (!ACT) {
+                        if (third) {                         // what smx_dropout_colsum would compute from the stored dx
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = rt(o[e], dx);
+                            smx_drop_mul8(p.drop2_seed, (unsigned)((long long)row * p.D + c), th2, inv2, o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                o[e] = rt(o[e], dx);
+                                dc[j][e] += o[e];
+                            }
+                            store8(reinterpret_cast<T*>(p.dx_drop) + (long long)row * p.D + c, o);
+                        }
+                    }
                 }
             }
         }
@@ -354,17 +381,17 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
     for (int j = 0; j < LN_NCH; ++j) {
         if (64 * 8 * j >= p.D) break;
         const int c = (lane + 64 * j) * 8;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        const int npass = third ? 3 : 2;
+        for (int pass = 0; pass < npass; ++pass) {
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[w][lane][e] = pass == 0 ? dg[j][e] : db[j][e];
+            for (int e = 0; e < 8; ++e) red[w][lane][e] = pass == 0 ? dg[j][e] : pass == 1 ? db[j][e] : dc[ACT ? 0 : j][e];
             __syncthreads();
             if (w == 0 && c < p.D) {
                 float sum8[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum8[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
-                store8(p.partials + ((long long)blockIdx.x * 2 + pass) * p.D + c, sum8);
+                store8(p.partials + ((long long)blockIdx.x * npass + pass) * p.D + c, sum8);
             }
         }
     }
@@ -550,6 +577,8 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     if (p.dpos && p.pos_period <= 0) return SMX_EINVAL;
     if (dtype != SMX_F32 && dtype != SMX_BF16) return SMX_EINVAL;
     if ((p.dgamma || p.dbeta) && !p.partials) return SMX_EINVAL;
+    if (p.dx_drop && (!p.defer_fold || !p.partials || !(p.dgamma || p.dbeta) || p.act != SMX_ACT_NONE || p.drop2_p < 0.f || p.drop2_p >= 1.f))
+        return SMX_EINVAL;
     const bool act = p.act != SMX_ACT_NONE;
     dim3 grid((p.M + 3) / 4);
     static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');      // A/B switch
@@ -559,7 +588,7 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
         if (dtype == SMX_F32) {
             if (act) hipLaunchKernelGGL((norm_bwd_fused_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((norm_bwd_fused_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, p);
-        } else if (raw_mode == 1 || (raw_mode < 0 && p.D <= 512)) {      // narrow rows: see norm_bwd_fused_raw_kernel
+        } else if (!p.dx_drop && (raw_mode == 1 || (raw_mode < 0 && p.D <= 512))) {      // narrow rows: see norm_bwd_fused_raw_kernel
             if (act) hipLaunchKernelGGL((norm_bwd_fused_raw_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((norm_bwd_fused_raw_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
         } else {

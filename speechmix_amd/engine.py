@@ -332,15 +332,29 @@ class Engine:
         return y, (xs if want_sum else x, mean, rstd, drop)
 
     def ln_bwd(self, dy, saved, wname, bname, M, D, rms=False, act=ACT_NONE, dres=None, dpos=None, pos_period=0,
-               pos_offset=0, dx=None):
+               pos_offset=0, dx=None, fuse=None):
+        """fuse = dict(drop=(p, seed), gb=bias gradient) of the Linear whose dropped output fed this norm (post-LN layers): the
+        kernel then also writes dx * mask into fuse["out"] and queues its column sums into gb (see ops.norm_bwd)."""
         x, mean, rstd, drop = saved
         dx = dx if dx is not None else self.new(M, D)
         train = self.tr(wname)
+        extra = {}
+        if (fuse is not None and train and self.folds is not None and act == ACT_NONE and not (D & 7)
+                and os.environ.get("SMX_FUSE_LN_DROPCOL") != "0"):
+            fuse["out"] = self.new(M, D)
+            extra = dict(drop2=fuse["drop"], dx_drop=fuse["out"], gb2=fuse["gb"])
         ops.norm_bwd(dy, x, dx, self.P(wname), self.P(bname) if bname else None, mean, rstd,
                      self.G(wname) if train else None, self.G(bname) if (bname and train) else None, M, D, self.dt,
                      rms=rms, act=act, dres=dres, dpos=dpos, pos_period=pos_period, pos_offset=pos_offset, drop=drop,
-                     folds=self.folds)
+                     folds=self.folds, **extra)
         return dx
+
+    def _fuse_site(self, drop, wname, bname, N):
+        """-> the `fuse` argument of ln_bwd for a dropped Linear (weight wname, bias bname, N outputs), or None when its
+        masked gradient / bias gradient cannot ride in the norm's backward (no dropout, no trainable bias)."""
+        if drop is None or not bname or not self.tr(wname) or (N & 7):
+            return None
+        return dict(drop=drop, gb=self.G(bname))
 
     # ------------------------------------------------------------------ attention block (self or cross)
     def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None, drop=None):
@@ -449,13 +463,17 @@ class Engine:
                      av=fv if Fp != F else None)
         return y, (h, pre, f, d_act, d_out, act)
 
-    def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid):
-        """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid)."""
+    def _ffn_bwd(self, dy, sv, M, d, F, n1, n2, act, dx_resid, dy_masked=None):
+        """dy: grad wrt fc2 output.  Returns grad wrt h (+ dx_resid).  dy_masked: dy * fc2's output-dropout mask with the bias
+        gradient already queued (ln_bwd's `fuse`)."""
         h, pre, f, d_act, d_out, act = sv            # (act as the forward used it: may carry ACT_SAVE_GRAD)
         Fp = self._pad_ld(F)
         fv = view(Fp) if Fp != F else None
         gb = self.G(n2[1]) if (n2[1] and self.tr(n2[0])) else None
-        dy, fused = self._dropped(dy, d_out, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, d_out, M * d), False)
+        if dy_masked is not None:
+            dy, fused = dy_masked, True
+        else:
+            dy, fused = self._dropped(dy, d_out, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, d_out, M * d), False)
         if self.tr(n2[0]):
             self.wgrad(dy, f, self.G(n2[0]), M, d, F, gb=None if fused else gb, xv=fv)
         dpre = self.new(M, Fp)
@@ -507,11 +525,14 @@ class Engine:
     def _b(self, n):
         return self.P(n) if n else None
 
-    def _oproj_bwd(self, dy, sv_attn, names, M, d, drop=None):
-        """dy: grad wrt the (dropped) out_proj output; returns grad wrt attention output o."""
+    def _oproj_bwd(self, dy, sv_attn, names, M, d, drop=None, dy_masked=None):
+        """dy: grad wrt the (dropped) out_proj output; returns grad wrt attention output o.  dy_masked: see _ffn_bwd."""
         wn, bn = names["o"]
         gb = self.G(bn) if (bn and self.tr(wn)) else None
-        dy, fused = self._dropped(dy, drop, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, drop, M * d), False)
+        if dy_masked is not None:
+            dy, fused = dy_masked, True
+        else:
+            dy, fused = self._dropped(dy, drop, M * d, bias_grad=gb, N=d) if gb is not None else (self._dropped(dy, drop, M * d), False)
         if self.tr(wn):
             self.wgrad(dy, sv_attn["o"], self.G(wn), M, d, d, gb=None if fused else gb)
         do = self.new(M, d)
@@ -522,14 +543,19 @@ class Engine:
         B, T, d, H, F = sv["dims"]
         M = B * T
         if not pre_ln:
-            ds3 = self.ln_bwd(dy, sv["ln2"], nm["ln2"][0], nm["ln2"][1], M, d)
-            dh = self._ffn_bwd(ds3, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, ds3)
+            # post-LN: every norm's input is x + dropout(Linear(...)), so the norm's backward also emits the masked gradient
+            # that enters that Linear and its bias gradient (ln_bwd `fuse`; otherwise _dropped does it in a pass of its own)
+            fz = self._fuse_site(sv["f"][4], nm["fc2"][0], nm["fc2"][1], d)
+            ds3 = self.ln_bwd(dy, sv["ln2"], nm["ln2"][0], nm["ln2"][1], M, d, fuse=fz)
+            dh = self._ffn_bwd(ds3, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, ds3, dy_masked=fz.get("out") if fz else None)
             if "x" in sv:
-                ds2 = self.ln_bwd(dh, sv["lnx"], nm["lnx"][0], nm["lnx"][1], M, d)
-                do2 = self._oproj_bwd(ds2, sv["x"], nm["xattn"], M, d, sv["d_xo"])
+                fz = self._fuse_site(sv["d_xo"], nm["xattn"]["o"][0], nm["xattn"]["o"][1], d)
+                ds2 = self.ln_bwd(dh, sv["lnx"], nm["lnx"][0], nm["lnx"][1], M, d, fuse=fz)
+                do2 = self._oproj_bwd(ds2, sv["x"], nm["xattn"], M, d, sv["d_xo"], dy_masked=fz.get("out") if fz else None)
                 dh = self.attn_bwd(do2, sv["x"], nm["xattn"], dx_resid=ds2, dkv_accum=denc)
-            ds1 = self.ln_bwd(dh, sv["ln1"], nm["ln1"][0], nm["ln1"][1], M, d)
-            do = self._oproj_bwd(ds1, sv["a"], nm["attn"], M, d, sv["d_o"])
+            fz = self._fuse_site(sv["d_o"], nm["attn"]["o"][0], nm["attn"]["o"][1], d)
+            ds1 = self.ln_bwd(dh, sv["ln1"], nm["ln1"][0], nm["ln1"][1], M, d, fuse=fz)
+            do = self._oproj_bwd(ds1, sv["a"], nm["attn"], M, d, sv["d_o"], dy_masked=fz.get("out") if fz else None)
             return self.attn_bwd(do, sv["a"], nm["attn"], dx_resid=ds1, dbias=dbias)
         # pre-LN: y = x1 + ffn(LN2(x1)); x1 = x(+cross) + attn(LN1(x))
         dn2 = self._ffn_bwd(dy, sv["f"], M, d, F, nm["fc1"], nm["fc2"], act, None)

@@ -362,12 +362,20 @@ class FoldQueue:
 
 
 def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms=False, act=ACT_NONE, dres=None,
-             dpos=None, pos_period=0, pos_offset=0, drop=None, folds=None):
-    """folds: a FoldQueue - the gamma / beta partial rows are then reduced at its next flush instead of by a launch here."""
+             dpos=None, pos_period=0, pos_offset=0, drop=None, folds=None, drop2=None, dx_drop=None, gb2=None):
+    """folds: a FoldQueue - the gamma / beta partial rows are then reduced at its next flush instead of by a launch here.
+    drop2 = (p, seed), dx_drop, gb2 (needs folds and dgamma / dbeta): also writes dx * mask(drop2) and queues its column
+    sums into gb2 (the bias gradient of the Linear whose dropped output fed this norm) - one pass instead of a separate
+    smx_dropout_colsum over dx."""
     ws = None
     rows = (M + 15) // 16
+    third = dx_drop is not None
+    nrow = 3 if third else 2
+    if third:
+        if folds is None or (dgamma is None and dbeta is None) or drop2 is None or gb2 is None:
+            raise RuntimeError("norm_bwd: dx_drop needs a FoldQueue, gamma / beta gradients, drop2 and gb2")
     if dgamma is not None or dbeta is not None:
-        need = rows * 2 * D
+        need = rows * nrow * D
         if folds is not None:
             ws = torch.empty(need, dtype=torch.float32, device=dy.device)
         else:
@@ -380,14 +388,18 @@ def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms
         p.drop_p, p.drop_seed = drop
     if folds is not None and ws is not None:
         p.defer_fold = 1
-    with _Span("norm_bwd", M * D * _es(dtype) * (4 if dres is not None else 3)):
+    if third:
+        p.dx_drop, p.drop2_p, p.drop2_seed = _ptr(dx_drop), drop2[0], drop2[1]
+    with _Span("norm_bwd", M * D * _es(dtype) * ((4 if dres is not None else 3) + (1 if third else 0))):
         L.check(L.lib().smx_norm_bwd(C.byref(p), dtype, _stream()), "smx_norm_bwd")
     if folds is not None and ws is not None:
         assert rows == L.lib().smx_norm_bwd_partial_rows(M)
         if dgamma is not None:
-            folds.add(ws, 0, dgamma, rows, D, 2 * D)
+            folds.add(ws, 0, dgamma, rows, D, nrow * D)
         if dbeta is not None:
-            folds.add(ws, D, dbeta, rows, D, 2 * D)
+            folds.add(ws, D, dbeta, rows, D, nrow * D)
+        if third:
+            folds.add(ws, 2 * D, gb2, rows, D, nrow * D)
 
 
 _NORM_WS = {}

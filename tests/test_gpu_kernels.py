@@ -290,6 +290,46 @@ def test_grouped_weight_gradient_launch_equals_the_separate_launches():
         ops.gemm_group([(a, b, torch.zeros(M, N, dtype=torch.bfloat16, device=dev), M, N, K, dict(a_rc=True, b_rc=True, av=view(M), bv=view(N)))], ops.BF16)
 
 
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp32"])
+def test_norm_backward_emits_the_masked_gradient_and_bias_gradient_of_the_dropped_linear(dtype_name):
+    """Post-LN layers: the norm's input is x + dropout(Linear(...)), so its backward can also write dx * mask (the gradient
+    entering that Linear) and that Linear's bias gradient.  Must equal the two-step form (smx_norm_bwd, then
+    smx_dropout_colsum over the stored dx): the masked tensor bit for bit, the column sums up to fp32 summation order."""
+    import torch
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    dt, tdt = (ops.BF16, torch.bfloat16) if dtype_name == "bf16" else (ops.F32, torch.float32)
+    for (M, D) in ((1000, 768), (4099, 640), (130, 1024)):      # (D <= 512 takes another dx kernel: not bit-comparable)
+        g = torch.Generator().manual_seed(M)
+        x = torch.randn(M, D, generator=g).to(dev).to(tdt); dy = torch.randn(M, D, generator=g).to(dev).to(tdt)
+        dres = torch.randn(M, D, generator=g).to(dev).to(tdt)
+        gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev); beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+        y = torch.empty_like(x); mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+        ops.norm_fwd(x, y, gamma, beta, mean, rstd, M, D, dt)
+        drop2 = (0.1, 4242)
+        # two-step reference
+        f0 = ops.FoldQueue()
+        dx0 = torch.empty_like(x); dg0 = torch.zeros(D, device=dev); db0 = torch.zeros(D, device=dev)
+        ops.norm_bwd(dy, x, dx0, gamma, beta, mean, rstd, dg0, db0, M, D, dt, dres=dres, folds=f0)
+        m0 = torch.empty_like(x); gb0 = torch.zeros(D, device=dev)
+        ops.dropout_colsum(dx0, m0, M, D, drop2[0], drop2[1], gb0, dt, folds=f0)
+        f0.flush()
+        # fused
+        f1 = ops.FoldQueue()
+        dx1 = torch.empty_like(x); dg1 = torch.zeros(D, device=dev); db1 = torch.zeros(D, device=dev)
+        m1 = torch.empty_like(x); gb1 = torch.zeros(D, device=dev)
+        ops.norm_bwd(dy, x, dx1, gamma, beta, mean, rstd, dg1, db1, M, D, dt, dres=dres, folds=f1, drop2=drop2, dx_drop=m1, gb2=gb1)
+        f1.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(dx0, dx1) and torch.equal(m0, m1), (M, D)
+        for r0, r1 in ((dg0, dg1), (db0, db1)):          # same partial rows, folded in a launch of another shape
+            assert (r0 - r1).abs().max().item() <= 1e-5 * r0.abs().max().item() + 1e-6
+        assert gb0.abs().max().item() > 0
+        assert (gb0 - gb1).abs().max().item() <= 1e-5 * gb0.abs().max().item() + 1e-6, (M, D)
+    with pytest.raises(RuntimeError):                       # the third partial row exists only in the deferred-fold form
+        ops.norm_bwd(dy, x, dx1, gamma, beta, mean, rstd, dg1, db1, M, D, dt, drop2=drop2, dx_drop=m1, gb2=gb1, folds=None)
+
+
 def test_half_height_tiles_of_the_128_kernel_are_bit_identical_to_it():
     """tr_mode 9 (64 x 128 tiles: twice the workgroups for launches that leave most resident slots empty) runs the same
     K order and the same epilogue arithmetic as tr_mode 1, so every instantiated class must agree bit for bit: forward
