@@ -213,8 +213,10 @@ struct DmaLoader {
     }
     // ASM: issue through inline asm so that hipcc does not drain the DMA queue (s_waitcnt vmcnt(0)) before the next
     // LDS read - the pipelined kernels count their own waits
-    template <bool ASM = false>
-    __device__ __forceinline__ void issue(char* tile, const SmxRowView& v, int row0, int nrows, int k0, int K, int tid) {
+    // rcp0 / RCNP: the 16-k-row passes of a rows-contiguous tile this caller issues (the eight-wave kernel gives each half of
+    // the workgroup two of the four; rcp0 is wave-uniform)
+    template <bool ASM = false, int RCNP = 4>
+    __device__ __forceinline__ void issue(char* tile, const SmxRowView& v, int row0, int nrows, int k0, int K, int tid, int rcp0 = 0) {
         const int lane = tid & 63, wave = tid >> 6;
         if (!RC) {
             const bool kin = k0 + kc < K;
@@ -226,8 +228,12 @@ struct DmaLoader {
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int kl = p * 16 + wave * 4 + (lane >> 4);
+            for (int pp = 0; pp < RCNP; ++pp) {
+                const int p = rcp0 + pp;
+                int kl = p * 16 + wave * 4 + (lane >> 4);
+                // (eight-wave kernel, 128 registers with a second loader beside this one: keep the per-pass row products out
+                // of the registers that live across the K loop - they are one 64-bit multiply-add to recompute)
+                if constexpr (RCNP != 4) asm volatile("" : "+v"(kl));
                 const int g16 = lane & 15;
                 const int c = row0 + ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
                 const bf16_t* src = zero;
@@ -579,6 +585,105 @@ __global__ __launch_bounds__(256, TR1_MINWG) void gemm_bf16_dma_kernel(SmxGemmPa
     }   // tile loop
 }
 
+// ------------------------------------------------------------------------------------------------
+// Eight waves on a 256 x 128 tile, two workgroups per CU (tr_mode 11).  The kernel above moves 128 KB into LDS per CU and K
+// step (four 32-KB tiles), and its K loop runs at exactly the rate that volume is delivered (~42 B/clk/CU); this form keeps
+// its structure - independent single-stage workgroups hiding each other's fills, 64 x 64 wave tiles, the same epilogue - on
+// tiles that need 25 % fewer bytes per flop (48 KB per 256 x 128 x 64).  Measured against it (tools/lab/gemm16w_lab.hip, same
+// loader / fragment / epilogue code, bit-identical results): +13 % on 16 k x 3072 x 768, +8 % on 16 k x 768 x 3072, +22 % on
+// 16 k x 4096 x 1024, equal or worse where 256-row tiles quantise badly; the tuner picks per shape.  K-contiguous A, no split-K,
+// classes with the specialised epilogue.
+// ------------------------------------------------------------------------------------------------
+template <bool B_RC, int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_dma8_kernel(SmxGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];            // 64 KB: 48 KB of tiles, 8 x 8 KB epilogue slices
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int q = wave >> 2, tq = tid & 255;          // loader role: half q fills A rows 128 q .. and its half of the B tile
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + 255) / 256;
+    const int nwg = ntn * ntm;
+    for (int lin = blockIdx.x; lin < nwg; lin += gridDim.x) {
+        int wg = lin;
+        {
+            const int qq = nwg >> 3, r = nwg & 7, x = wg & 7, y = wg >> 3;
+            wg = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + y;
+        }
+        int tm, tn;
+        {
+            const int per_group = GROUP_N * ntm;
+            const int grp = wg / per_group, rem = wg - grp * per_group;
+            const int first = grp * GROUP_N;
+            const int gsz = min(ntn - first, GROUP_N);
+            tm = rem / gsz;
+            tn = first + (rem - tm * gsz);
+        }
+        const int m0 = tm * 256, n0 = tn * BN;
+        const int z = blockIdx.z;
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long long)z * p.batch_a;
+        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B) + (long long)z * p.batch_b;
+        const long long zc = (long long)z * p.batch_c, zbias = (long long)z * p.batch_bias, ze = (long long)z * p.batch_e;
+        const int ks1 = (p.K + BK - 1) / BK;
+        DmaLoader<false> la;
+        DmaLoader<B_RC, 2> lb;              // K-contiguous B: my 64 of its 128 rows; rows-contiguous B: two of its four k-row passes
+        la.init(A, p.a, m0 + q * 128, p.M, 0, tq);
+        lb.init(B, p.b, B_RC ? n0 : n0 + q * 64, p.N, 0, tq);
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        char* tA = smem + (wm >> 1) * 16384;
+        char* tB = smem + 32768;
+        const bool wave_on = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
+        for (int ks = 0; ks < ks1; ++ks) {
+            la.issue(smem + q * 16384, p.a, m0 + q * 128, p.M, ks * BK, p.K, tq);
+            if constexpr (B_RC) {
+                lb.template issue<false, 2>(tB, p.b, n0, p.N, ks * BK, p.K, tq, 2 * q);
+            } else {
+                lb.issue(tB + q * 8192, p.b, n0 + q * 64, p.N, ks * BK, p.K, tq);
+            }
+            __syncthreads();                 // (the compiler drains the LDS-DMA queue before the barrier)
+            if (wave_on) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    bf16x8_t fa[4], fb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i] = load_frag<false>(tA, (wm & 1) * 64 + i * 16, kk, lane, 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[j] = load_frag<B_RC>(tB, wn * 64 + j * 16, kk, lane, 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();                 // everyone is done reading before the next fill overwrites the tile
+        }
+        {
+            int lane_e = lane, wave_e = wave;
+            asm volatile("" : "+v"(lane_e), "+v"(wave_e));
+            wave_e = __builtin_amdgcn_readfirstlane(wave_e);
+            auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const SmxGemmParams& pe = *(const SmxGemmParams*)ka;
+            if (wave_on)
+                epilogue_staged_fast<EPI, 0>(pe, acc, smem + wave_e * 8192, m0 + (wave_e >> 1) * 64, n0 + (wave_e & 1) * 64, zc, zbias, ze, lane_e);
+        }
+        if (lin + (int)gridDim.x < nwg) __syncthreads();   // slices are tile memory again for the next fill
+    }
+}
+
+template <bool B_RC, int EPI>
+static void dma8_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
+    static bool attr_done = false;          // (once per instantiation: the attribute call costs tens of microseconds of host time)
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_dma8_kernel<B_RC, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_dma8_kernel<B_RC, EPI>), grid, dim3(512), 65536, stream, p);
+}
+
 int smx_gemm_pp(const SmxGemmParams& p, hipStream_t stream);   // gemm_pp.hip
 
 // ------------------------------------------------------------------------------------------------
@@ -791,6 +896,28 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
     if ((p.tr_mode & 255) == 8) return smx_gemm_pp(p, stream);        // 256 x 256, persistent ping-pong
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
+    if (p.tr_mode == 11) {    // 256 x 128 tiles, eight waves, two workgroups per CU (gemm_bf16_dma8_kernel)
+        const bool flagged = (p.act & SMX_ACT_SAVE_GRAD) != 0;
+        const int epi = (p.atomic == 0 && smx_epi_views_aligned(p)) ? pp_epi_class(p) : -1;
+        if (p.a_rc || p.split_k != 1 || epi < 0 || epi == PP_EPI_F32) return SMX_EINVAL;
+        dim3 g11(((p.M + 255) / 256) * ((p.N + BN - 1) / BN), 1, p.nbatch);
+        if (g11.x > 512) g11.x = 512;
+        p.tr_mode = 1;
+#define TR11_GO(BR, E) dma8_launch<BR, E>(p, g11, stream)
+        if (!p.b_rc) {
+            if (epi == PP_EPI_LINEAR) TR11_GO(false, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACT && flagged) TR11_GO(false, 4);
+            else if (epi == PP_EPI_ACT) TR11_GO(false, PP_EPI_ACT);
+            else return SMX_EINVAL;
+        } else {
+            if (epi == PP_EPI_LINEAR) TR11_GO(true, PP_EPI_LINEAR);
+            else if (epi == PP_EPI_ACTGRAD && flagged && !p.bias) TR11_GO(true, 5);
+            else if (epi == PP_EPI_ACTGRAD && !flagged) TR11_GO(true, PP_EPI_ACTGRAD);
+            else return SMX_EINVAL;
+        }
+#undef TR11_GO
+        SMX_CHECK_LAUNCH();
+    }
     if (p.tr_mode == 9) {     // 64 x 128 tiles of the same kernel (gemm_bf16_dma_kernel<.., BMH = 1>): K-contiguous A, aligned classes
         const bool flagged = (p.act & SMX_ACT_SAVE_GRAD) != 0;
         const int epi = (p.atomic == 0 && smx_epi_views_aligned(p)) ? pp_epi_class(p) : -1;

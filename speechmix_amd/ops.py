@@ -143,8 +143,22 @@ def _half_applicable(p, dtype):
     return tiles < 640
 
 
+W8_MODE = os.environ.get("SMX_GEMM_W8", "auto")       # 256 x 128 tiles, eight waves, two workgroups / CU (tr_mode 11): auto | 0 | 1
+
+
+def _w8_applicable(p, dtype):
+    """tr_mode 11 covers K-contiguous A operands, bf16 outputs of the aligned epilogue classes, no split-K; it needs enough
+    256 x 128 tiles to occupy the 512 resident workgroup slots."""
+    if W8_MODE == "0" or dtype != L.BF16 or p.a_rc or p.split_k != 1 or p.out_f32 or p.atomic:
+        return False
+    if (p.N & 7) or ((p.c.ld | p.c.off | p.e.ld | p.e.off) & 7) or (p.b_rc and p.b.rows_per_batch > 0) or p.a.rows_per_batch > 0:
+        return False
+    tiles = ((p.M + 255) // 256) * ((p.N + 127) // 128) * max(p.nbatch, 1)
+    return tiles >= 360
+
+
 def _choose_mode(p, dtype):
-    """-> tr_mode for this launch: 1 (128x128), 8 (ping-pong) or 9 (64x128)."""
+    """-> tr_mode for this launch: 1 (128x128), 8 (ping-pong), 9 (64x128) or 11 (256x128, eight waves)."""
     cands = [1]
     if pp_allowed() and _pp_applicable(p, dtype):
         if PP_MODE == "1":
@@ -154,6 +168,10 @@ def _choose_mode(p, dtype):
         if HALF_MODE == "1":
             return 9
         cands.append(9)
+    if _w8_applicable(p, dtype):
+        if W8_MODE == "1":
+            return 11
+        cands.append(11)
     if len(cands) == 1:
         return 1
     key = (tuple(cands), pp_cus(), p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
@@ -172,7 +190,7 @@ def _choose_mode(p, dtype):
                     pass
             mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else 1.03))      # ties go to the 128x128 kernel
             if TUNE_LOG is not None:
-                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9)))
+                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11)))
         _TUNED[key] = mode
     return mode
 
@@ -230,7 +248,7 @@ class GemmProfile:
     def name(key):
         a, b, mode = key
         kern = "gemm_bf16_pp_kernel" if mode == 8 else "gemm_bf16_dma_kernel"
-        tile = ", 64x128 tiles" if mode == 9 else ""
+        tile = ", 64x128 tiles" if mode == 9 else ", 256x128 tiles" if mode == 11 else ""
         return f"{kern}<{str(bool(a)).lower()},{str(bool(b)).lower()}> ({GemmProfile._ROLE[(a, b)]}{tile})"
 
     def __init__(self):

@@ -330,6 +330,54 @@ def test_norm_backward_emits_the_masked_gradient_and_bias_gradient_of_the_droppe
         ops.norm_bwd(dy, x, dx1, gamma, beta, mean, rstd, dg1, db1, M, D, dt, drop2=drop2, dx_drop=m1, gb2=gb1, folds=None)
 
 
+def test_eight_wave_256x128_kernel_is_bit_identical_to_the_128_kernel():
+    """tr_mode 11 (256 x 128 tiles, eight waves, two workgroups per CU: 25 % fewer bytes into LDS per flop) runs the same K
+    order and epilogue arithmetic as tr_mode 1: every instantiated class must agree bit for bit - forward LINEAR / ACT / ACT
+    with the saved derivative, data gradient LINEAR / ACTGRAD / saved-derivative form - incl. ragged edges and a batched launch."""
+    import torch
+    from speechmix_amd import ops
+    from speechmix_amd.ops import ACT_GELU, view
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    for (M, N, K) in ((15968, 768, 3072), (8000, 3072, 768), (1000, 200, 192), (300, 1536, 256)):
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        Wt = W.t().contiguous()
+        bias = torch.randn(N, device=dev) * 0.1
+        R = torch.randn(M, N, device=dev).bfloat16()
+        S = torch.randn(M, N, device=dev).bfloat16()
+        cases = {
+            "linear": dict(bias=bias, resid=R, drop=(0.1, 7)),
+            "act": dict(bias=bias, act=ACT_GELU, aux_out="aux", drop=(0.1, 8)),
+            "act_saved": dict(bias=bias, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out="aux", drop=(0.1, 9)),
+            "dgrad": dict(b_rc=True, bv=view(N), resid=R),
+            "dgrad_actgrad": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU, drop=(0.1, 10)),
+            "dgrad_saved": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU | ops.ACT_SAVE_GRAD),
+        }
+        for name, kw in cases.items():
+            outs = []
+            for mode in (1, 11):
+                Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                aux = torch.zeros_like(Y)
+                k2 = {k: (aux if isinstance(v, str) else v) for k, v in kw.items()}
+                ops.gemm(A, Wt if kw.get("b_rc") else W, Y, M, N, K, ops.BF16, tr_mode=mode, **k2)
+                outs.append((Y, aux))
+            assert torch.equal(outs[0][0], outs[1][0]), (name, M, N, K)
+            assert torch.equal(outs[0][1], outs[1][1]), (name, M, N, K)
+            assert outs[0][0].float().abs().max().item() > 0
+    # batched (grid.z) launch
+    G, M, N, K = 3, 700, 256, 320
+    A = torch.randn(G, M, K, device=dev).bfloat16(); W = (torch.randn(G, N, K, device=dev) * 0.05).bfloat16()
+    outs = []
+    for mode in (1, 11):
+        Y = torch.zeros(G, M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, Y, M, N, K, ops.BF16, nbatch=G, batch_a=M * K, batch_b=N * K, batch_c=M * N, tr_mode=mode)
+        outs.append(Y)
+    assert torch.equal(outs[0], outs[1]) and outs[0].float().abs().max().item() > 0
+    with pytest.raises(RuntimeError):
+        ops.gemm(A[0], W[0], torch.zeros(M, N, dtype=torch.float32, device=dev), M, N, K, ops.BF16, out_f32=True, tr_mode=11)
+
+
 def test_half_height_tiles_of_the_128_kernel_are_bit_identical_to_it():
     """tr_mode 9 (64 x 128 tiles: twice the workgroups for launches that leave most resident slots empty) runs the same
     K order and the same epilogue arithmetic as tr_mode 1, so every instantiated class must agree bit for bit: forward

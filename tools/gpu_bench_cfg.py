@@ -28,6 +28,9 @@ if __name__ == "__main__":
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     mode = sys.argv[4] if len(sys.argv) > 4 else "train"
     model = build(cfg)
+    if os.environ.get("SMX_TUNE_DUMP"):
+        from speechmix_amd import ops as _ops
+        _ops.TUNE_LOG = []
     model.train(mode == "train")
     V = model.decoder_model.config.vocab_size
     g = torch.Generator().manual_seed(0)
@@ -44,6 +47,11 @@ if __name__ == "__main__":
         loss = runner.step(wave, labels, text_input_ids=text)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if os.environ.get("SMX_TUNE_DUMP"):
+        us = lambda t: f"{t*1e3:8.1f}" if t is not None else "       -"
+        for rec in _ops.TUNE_LOG:
+            key, t1, t8, mode, *rest = rec
+            print("tune", us(t1), us(t8), *(us(r) for r in rest), "->", mode, key[:10] if isinstance(key[0], tuple) else key, file=sys.stderr)
     print(json.dumps({"config": int(cfg), "workload": NAMES[cfg], "mode": mode, "batch": B, "clip_seconds": 10.0, "steps": steps,
                       "ms_per_step": round(dt * 1e3, 2), "audio_s_per_s": round(B * 10 / dt, 1), "dtype": "bf16",
                       "optimizer": "adafactor", "params_M": round(model.store.total / 1e6, 1), "peak_mem_GB": round(mem, 1),
