@@ -151,7 +151,7 @@ def _w8_applicable(p, dtype):
     256 x 128 tiles to occupy the 512 resident workgroup slots."""
     if W8_MODE == "0" or dtype != L.BF16 or p.a_rc or p.split_k != 1 or p.out_f32 or p.atomic:
         return False
-    if (p.N & 7) or ((p.c.ld | p.c.off | p.e.ld | p.e.off) & 7) or (p.b_rc and p.b.rows_per_batch > 0) or p.a.rows_per_batch > 0:
+    if (p.N & 7) or ((p.c.ld | p.c.off | p.e.ld | p.e.off) & 7):
         return False
     tiles = ((p.M + 255) // 256) * ((p.N + 127) // 128) * max(p.nbatch, 1)
     return tiles >= 360
