@@ -254,12 +254,22 @@ def main():
             if not os.path.exists(pmc):
                 pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
             if os.path.exists(pmc):
-                # PMC keys carry every template argument ("gemm_bf16_pp_kernel<true,true,3,0,false>"): match on the kernel
-                # name and its two layout arguments, launch-weighted over the instantiations
-                base = kname.split(" ")[0]
-                stem, targs = base.split("<")[0], base.split("<")[1].rstrip(">")
-                hits = [v for k, v in json.load(open(pmc))["kernels"].items()
-                        if k.split("<")[0] == stem and k.split("<")[1].startswith(targs)]
+                # PMC keys carry every template argument ("gemm_bf16_pp_kernel<true,true,3,0,false>"): pick the instantiations
+                # that make up this profile variant (a_rc, b_rc, tr_mode), launch-weighted
+                a_rc, b_rc, mode = dom
+                ab = ("true" if a_rc else "false", "true" if b_rc else "false")
+
+                def in_variant(key):
+                    stem, targs = key.split("<")[0], key.split("<")[1].rstrip(">").split(",")
+                    if mode == 8:            # ping-pong kernel, incl. the grouped weight-gradient launches
+                        return stem in ("gemm_bf16_pp_kernel", "gemm_bf16_pp_group_kernel") and tuple(targs[:2]) == ab
+                    if mode == 11:           # eight-wave kernel: <B_RC, EPI>, A always K-contiguous
+                        return stem == "gemm_bf16_dma8_kernel" and not a_rc and targs[0] == ab[1]
+                    if stem != "gemm_bf16_dma_kernel" or tuple(targs[:2]) != ab:
+                        return False
+                    bmh = targs[3] if len(targs) > 3 else "2"       # (round-1 files: three arguments)
+                    return bmh == ("1" if mode == 9 else "2")
+                hits = [v for k, v in json.load(open(pmc))["kernels"].items() if "<" in k and in_variant(k)]
                 n = sum(v["launches"] for v in hits)
                 if n:
                     line["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / n)
