@@ -64,6 +64,7 @@ def _gemm_params(a, b, c, M, N, K, a_rc=False, b_rc=False, av=None, bv=None, cv=
 # SMX_GEMM_PP = auto (default) | 0 (128x128 only) | 1 (ping-pong whenever it is applicable).
 PP_MODE = os.environ.get("SMX_GEMM_PP", "auto")
 _TUNED = {}
+_TUNE_MARGIN = float(os.environ.get("SMX_TUNE_MARGIN", "1.03"))     # a challenger must beat the 128x128 kernel by this factor
 # The ping-pong kernel needs a whole CU per workgroup (160 KB of LDS, the full register file).  A kernel running beside it
 # - RCCL's all-reduce of the gradient buckets on the side stream during backward - takes CUs away, and the displaced
 # workgroups then run as a second round (up to 2x the launch time), where the 4-workgroup/CU kernel only loses a quarter of
@@ -190,7 +191,7 @@ def _choose_mode(p, dtype):
                     except RuntimeError:          # a class the variant is not instantiated for
                         continue
                     times[m] = min(times.get(m, t), t)
-            mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else 1.03))      # ties go to the 128x128 kernel
+            mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else _TUNE_MARGIN))      # ties go to the 128x128 kernel
             if TUNE_LOG is not None:
                 TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11)))
         _TUNED[key] = mode
