@@ -153,9 +153,12 @@ __device__ __forceinline__ void glds16_asm(const bf16_t* src, const char* lds_wa
 // (ASM_ST) so that no compiler-tracked VMEM operation is pending when its K loop starts: with tracked stores in
 // flight hipcc drains the whole queue - its LDS-DMA prefetches included - before the first LDS read of every K tile.
 typedef __attribute__((ext_vector_type(4))) unsigned smx_u32x4_t;
+// A store of more than 8 bytes reads its data registers for a few cycles after issue: a VALU write of one of them
+// needs two wait states behind it (hipcc pads its own stores, it cannot see inside the asm) - without the s_nop a temporary
+// written right behind the store showed up in 4 lanes of the output (found with the free-running schedule, round 3).
 __device__ __forceinline__ void st_b128(void* p, uint4 v) {
     const smx_u32x4_t r = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(r) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
 }
 __device__ __forceinline__ void st_b32(void* p, unsigned v) {
     asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");

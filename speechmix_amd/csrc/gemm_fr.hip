@@ -1,0 +1,247 @@
+// ------------------------------------------------------------------------------------------------
+// bf16 "free-running" GEMM (tr_mode 12): the ping-pong kernel's tile (256 x 256 x 64, 8 waves as 2 x 4, wave tile 128 x 64,
+// one persistent workgroup per CU), LDS unit images, flat LDS-DMA unit stream, work list and register epilogues (gemm_pp.h),
+// under a different schedule.
+//
+// Why (tools/lab/cu_lab.hip, round 3): one wave reads LDS at no more than ~33-40 B/clk (a CU: 224 B/clk from 8 waves) and
+// issues at most one 1-KB LDS-DMA per ~50 clk, while LDS reads and LDS-DMA writes do not slow each other down (230 + 64
+// B/clk/CU together).  The ping-pong schedule concentrates a wave's 24 fragment reads and 8 DMA issues per K tile in its
+// four load segments (12 KB in the first one: ~370 clk at the per-wave rate against the partner's 256-clk MFMA segment)
+// and pays 16 barriers per K tile.  Here every wave runs ONE stream in which the fragment reads of the next 32-deep half
+// step and the LDS-DMA of the K tile after next are spread between the MFMAs of the current half step (12 B/clk per wave
+// on average), the two waves of a SIMD fill each other's issue stalls, and the workgroup meets at ONE barrier per K tile:
+//
+//   tile t (stage t & 1):  H0  32 MFMAs (k 0..31)  | reads: tile t, k 32..63
+//                          SYNC  s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier     -> tile t+1 landed for everyone, stage t & 1 free
+//                          H1  32 MFMAs (k 32..63) | reads: tile t+1, k 0..31 | LDS-DMA: tile t+2 -> stage t & 1
+//
+// The unit stream runs across work items exactly as in the ping-pong kernel, so the first two K tiles of the next item
+// are in flight / resident while the epilogue runs.
+// ------------------------------------------------------------------------------------------------
+#include "gemm_pp.h"
+
+// Fragment registers: ten A slots of one 16-row block each (eight in use + two spares) and the two B column halves
+// (two permuted 16-column blocks each).  Nothing is double-buffered wholesale: a slot is re-read for the next half step
+// as soon as the last MFMA that uses it has been issued.
+struct FRFrags {
+    bf16x8_t a[10];
+    bf16x8_t b[2][2];
+};
+
+template <bool A_RC>
+__device__ __forceinline__ bf16x8_t fr_afrag(const char* stage, int blk, int kk, int wr, int lane) {      // blk = rh * 4 + a
+    return load_frag<A_RC>(stage + (blk >> 2) * PP_UNIT, wr * 64 + (blk & 3) * 16, kk, lane, 1);
+}
+template <bool B_RC>
+__device__ __forceinline__ bf16x8_t fr_bfrag(const char* stage, int ch, int j, int kk, int wc, int lane) {
+    return pp_bfrag<B_RC>(stage + (2 + ch) * PP_UNIT, wc * 32, j, kk, lane);
+}
+// slot of A block `blk` in a half step of parity PAR (0: k 0..31, 1: k 32..63): blocks 6, 7 alternate between slots 6, 7 and 8, 9
+template <int PAR>
+__device__ __forceinline__ constexpr int fr_slot(int blk) { return (PAR && blk >= 6) ? blk + 2 : blk; }
+
+// One half step = two passes of 16 MFMAs: pass CH multiplies the eight A blocks with column half CH.
+//   pass 0:  at its start the B fragments of column half 1 of THIS half step are read (their registers were in use until the
+//            end of the previous pass); ISSUE0: two units of LDS-DMA.
+//   pass 1:  the fragments of the NEXT half step (k sub-step 1 - PAR of stage `nstage`) are read: column half 0 and the two
+//            spare-slot A blocks at its start, A blocks 0..5 each right after the last MFMA on its slot; ISSUE1: two units.
+// sched_barrier(0) after every A block pins the interleave.
+template <bool A_RC, bool B_RC, int PAR, int CH, bool READ, int ISSUE, class ISSUER>
+__device__ __forceinline__ void fr_pass(f32x4_t (&acc)[8][4], FRFrags& f, const char* stage, const char* nstage, ISSUER& is, int tid,
+                                        int lane, int wr, int wc) {
+    if constexpr (CH == 0) {
+        f.b[1][0] = fr_bfrag<B_RC>(stage, 1, 0, PAR, wc, lane);
+        f.b[1][1] = fr_bfrag<B_RC>(stage, 1, 1, PAR, wc, lane);
+    } else if constexpr (READ) {
+        f.b[0][0] = fr_bfrag<B_RC>(nstage, 0, 0, 1 - PAR, wc, lane);
+        f.b[0][1] = fr_bfrag<B_RC>(nstage, 0, 1, 1 - PAR, wc, lane);
+        f.a[fr_slot<1 - PAR>(6)] = fr_afrag<A_RC>(nstage, 6, 1 - PAR, wr, lane);
+        f.a[fr_slot<1 - PAR>(7)] = fr_afrag<A_RC>(nstage, 7, 1 - PAR, wr, lane);
+    }
+#ifdef FR_DBG_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int sl = fr_slot<PAR>(g);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[g][CH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[CH][j], f.a[sl], acc[g][CH * 2 + j], 0, 0, 0);
+        if constexpr (CH == 1 && READ) {
+            if (g < 6) f.a[g] = fr_afrag<A_RC>(nstage, g, 1 - PAR, wr, lane);
+        }
+#ifdef FR_DBG_WAIT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ISSUE != 0) {
+            if (g == 1) { if (ISSUE == 1) is.template issue<0>(tid); else is.template issue<2>(tid); __builtin_amdgcn_sched_barrier(0); }
+            if (g == 5) { if (ISSUE == 1) is.template issue<1>(tid); else is.template issue<3>(tid); __builtin_amdgcn_sched_barrier(0); }
+        }
+    }
+}
+
+// first half step of an item: nothing was prefetched across the epilogue
+template <bool A_RC, bool B_RC>
+__device__ __forceinline__ void fr_read_first(FRFrags& f, const char* stage, int wr, int wc, int lane) {
+    f.b[0][0] = fr_bfrag<B_RC>(stage, 0, 0, 0, wc, lane);
+    f.b[0][1] = fr_bfrag<B_RC>(stage, 0, 1, 0, wc, lane);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) f.a[g] = fr_afrag<A_RC>(stage, g, 0, wr, lane);
+}
+
+#define FR_SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <bool A_RC, bool B_RC, int EPI, bool BVIEW>
+__global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams pk) {
+    const SmxGemmParams& p = pp_kernarg();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntm = (p.M + PP_BM - 1) / PP_BM, ntn = (p.N + PP_BN - 1) / PP_BN;
+    const int W = ntm * ntn * p.nbatch * p.split_k;
+
+    PPIssue<A_RC, B_RC, BVIEW, false> is;
+    is.dv.init(p, ntm, ntn);
+    is.g = 0;
+    is.q = blockIdx.x; is.qstep = gridDim.x;
+    is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
+    is.wave_u = __builtin_amdgcn_readfirstlane(wave);
+    is.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    is.K = p.K;
+    is.load_item(tid);
+
+    // prologue: K tile 0 of the stream entirely, the first two units of tile 1; tile 0 is resident after the barrier
+    {
+        bool all = true;
+        all &= is.template issue<0>(tid);
+        all &= is.template issue<1>(tid);
+        all &= is.template issue<2>(tid);
+        all &= is.template issue<3>(tid);
+        all &= is.template issue<0>(tid);
+        all &= is.template issue<1>(tid);
+#ifdef FR_DBG_V0
+        all = false;
+#endif
+        if (all) PP_WAITV(4);
+        else PP_WAITV(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4_t acc[8][4];
+    FRFrags f;
+    int seq = 0, items = 0;
+    const bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
+    for (int q = blockIdx.x; q < W; q += gridDim.x) {
+        PPItem it;
+        pp_decode(pp_kernarg(), is.dv, q, it);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        ++items;
+        if (fast_epi && wr == 0) {          // bias slice of this item -> LDS (retired by the item's first SYNC)
+            const SmxGemmParams& pq = pp_kernarg();
+            if (pq.bias) {
+                pp_rsrc_t br = pp_make_rsrc(pq.bias + it.zbias + it.n0);
+                br[2] = max(pq.N - it.n0, 0) * 4;
+                pp_dma4(br, (unsigned)(wc * 64 + lane) * 4u, is.lds0 + PP_BIAS_OFF + (items & 1) * 1024 + wc * 256);
+            }
+        }
+        // the item's K tile 0 is resident: prologue barrier, or the SYNC inside the previous item's last half step
+        fr_read_first<A_RC, B_RC>(f, smem + (seq & 1) * PP_STAGE, wr, wc, lane);
+#ifdef FR_DBG_SYNCALL
+        FR_SYNC();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < it.nk; ++t) {
+            const char* cur = smem + (seq & 1) * PP_STAGE;
+            const char* oth = smem + ((seq & 1) ^ 1) * PP_STAGE;
+            // H0 (k 0..31 of tile t): pass 0 issues the last two units of stream tile seq+1, pass 1 reads k 32..63 of tile t
+            fr_pass<A_RC, B_RC, 0, 0, true, 2>(acc, f, cur, cur, is, tid, lane, wr, wc);
+#ifdef FR_DBG_SYNCALL
+            FR_SYNC();
+#endif
+            fr_pass<A_RC, B_RC, 0, 1, true, 0>(acc, f, cur, cur, is, tid, lane, wr, wc);
+#ifdef FR_DBG_SYNCALL
+            FR_SYNC();
+#endif
+            // H1 (k 32..63): pass 0; SYNC: stream tile seq+1 resident for everyone, every read of tile t done -> its stage is free;
+            // pass 1 reads k 0..31 of the item's next tile and issues the first two units of stream tile seq+2 into this stage
+            fr_pass<A_RC, B_RC, 1, 0, true, 0>(acc, f, cur, oth, is, tid, lane, wr, wc);
+            FR_SYNC();
+            // (in the item's last tile these reads fetch the next item's first fragments and are dropped: one copy of the pass)
+#ifdef FR_DBG_NOGARB
+            if (t + 1 < it.nk) fr_pass<A_RC, B_RC, 1, 1, true, 1>(acc, f, cur, oth, is, tid, lane, wr, wc);
+            else fr_pass<A_RC, B_RC, 1, 1, false, 1>(acc, f, cur, oth, is, tid, lane, wr, wc);
+#else
+            fr_pass<A_RC, B_RC, 1, 1, true, 1>(acc, f, cur, oth, is, tid, lane, wr, wc);
+#endif
+#ifdef FR_DBG_SYNCALL
+            FR_SYNC();
+#endif
+            ++seq;
+        }
+        if (fast_epi) {
+            pp_epilogue_fast<EPI, false>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
+                                         it.ze, lane, 0);
+        } else {
+            pp_epilogue<false>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool A_RC, bool B_RC, int EPI, bool BVIEW = false>
+static void fr_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_fr_kernel<A_RC, B_RC, EPI, BVIEW>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        attr_done[dev & 15] = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_fr_kernel<A_RC, B_RC, EPI, BVIEW>), grid, dim3(512), PP_LDS_BYTES, stream, p);
+}
+
+int smx_gemm_pp(const SmxGemmParams& p, hipStream_t stream);   // gemm_pp.hip
+
+int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
+    SmxGemmParams p = pin;
+    if (p.act & SMX_ACT_SAVE_GRAD) return SMX_EINVAL;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+        ncu &= ~7;
+    }
+    const long long W = (long long)((p.M + PP_BM - 1) / PP_BM) * ((p.N + PP_BN - 1) / PP_BN) * p.nbatch * p.split_k;
+    const int kst = (p.K + BK - 1) / BK, per = (kst + p.split_k - 1) / p.split_k;
+    if (W >= (1 << 22) || p.M >= (1 << 22) || p.N >= (1 << 22) || p.K >= (1 << 22) || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
+        ((p.K & 7) && !(p.a_rc && p.b_rc))) return SMX_EINVAL;
+    // batched views of rows-contiguous operands and the (RC, KC) layout: instantiated for the ping-pong schedule only
+    if ((p.a.rows_per_batch > 0 && p.a_rc) || (p.b.rows_per_batch > 0 && p.b_rc) || (p.a_rc && !p.b_rc)) return smx_gemm_pp(pin, stream);
+    const int cap = (p.tr_mode >> 16) & 0xfff;
+    const int wgs = cap > 0 && cap < ncu ? cap : ncu;
+    dim3 grid((unsigned)(W < wgs ? W : wgs));
+    const int epi = pp_epi_class(p);
+    p.tr_mode = 8;
+#define FR_GO(AR, BR, E) { if (epi == E) p.tr_mode |= 128; fr_launch<AR, BR, E>(p, grid, stream); SMX_CHECK_LAUNCH(); }
+    if (!p.a_rc && !p.b_rc) {
+        if (epi == PP_EPI_ACT) FR_GO(false, false, PP_EPI_ACT)
+        if (epi == PP_EPI_F32) FR_GO(false, false, PP_EPI_F32)
+        FR_GO(false, false, PP_EPI_LINEAR)
+    }
+    if (!p.a_rc && p.b_rc) {
+        if (epi == PP_EPI_ACTGRAD) FR_GO(false, true, PP_EPI_ACTGRAD)
+        if (epi == PP_EPI_F32) FR_GO(false, true, PP_EPI_F32)
+        FR_GO(false, true, PP_EPI_LINEAR)
+    }
+    if (p.a_rc && p.b_rc) FR_GO(true, true, PP_EPI_F32)
+    return SMX_EINVAL;
+#undef FR_GO
+}
