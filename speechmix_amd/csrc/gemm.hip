@@ -896,7 +896,7 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     if ((p.act & SMX_ACT_SAVE_GRAD) && ((p.tr_mode & 255) == 0 || (p.tr_mode & 255) == 2)) return SMX_EINVAL;   // production kernels only
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
     if ((p.tr_mode & 255) == 8) return smx_gemm_pp(p, stream);        // 256 x 256, persistent ping-pong
-    if ((p.tr_mode & 255) == 12) return smx_gemm_fr(p, stream);       // 256 x 256, persistent free-running schedule
+    if ((p.tr_mode & 255) == 12 || (p.tr_mode & 255) == 13) return smx_gemm_fr(p, stream);       // 256 x 256 / 192 x 256, persistent free-running schedule
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
     if (p.tr_mode == 11) {    // 256 x 128 tiles, eight waves, two workgroups per CU (gemm_bf16_dma8_kernel)
         const bool flagged = (p.act & SMX_ACT_SAVE_GRAD) != 0;

@@ -23,22 +23,25 @@
 // Fragment registers: ten A slots of one 16-row block each (eight in use + two spares) and the two B column halves
 // (two permuted 16-column blocks each).  Nothing is double-buffered wholesale: a slot is re-read for the next half step
 // as soon as the last MFMA that uses it has been issued.
+template <int NB>
 struct FRFrags {
-    bf16x8_t a[10];
+    bf16x8_t a[NB + 2];
     bf16x8_t b[2][2];
 };
 
-template <bool A_RC>
-__device__ __forceinline__ bf16x8_t fr_afrag(const char* stage, int blk, int kk, int wr, int lane) {      // blk = rh * 4 + a
-    return load_frag<A_RC>(stage + (blk >> 2) * PP_UNIT, wr * 64 + (blk & 3) * 16, kk, lane, 1);
+// A block blk = rh * 4 + a of my wave-row group (NB = 8: 128 rows, NB = 6: 96 rows - the second unit then holds 2 x 32 rows)
+template <bool A_RC, int NB>
+__device__ __forceinline__ bf16x8_t fr_afrag(const char* stage, int blk, int kk, int wr, int lane) {
+    return load_frag<A_RC>(stage + (blk >> 2) * PP_UNIT, wr * ((blk >> 2) && NB == 6 ? 32 : 64) + (blk & 3) * 16, kk, lane, 1);
 }
 template <bool B_RC>
 __device__ __forceinline__ bf16x8_t fr_bfrag(const char* stage, int ch, int j, int kk, int wc, int lane) {
     return pp_bfrag<B_RC>(stage + (2 + ch) * PP_UNIT, wc * 32, j, kk, lane);
 }
-// slot of A block `blk` in a half step of parity PAR (0: k 0..31, 1: k 32..63): blocks 6, 7 alternate between slots 6, 7 and 8, 9
-template <int PAR>
-__device__ __forceinline__ constexpr int fr_slot(int blk) { return (PAR && blk >= 6) ? blk + 2 : blk; }
+// slot of A block `blk` in a half step of parity PAR (0: k 0..31, 1: k 32..63): the last two blocks alternate between their own
+// slots and the two spare ones
+template <int PAR, int NB>
+__device__ __forceinline__ constexpr int fr_slot(int blk) { return (PAR && blk >= NB - 2) ? blk + 2 : blk; }
 
 // One half step = two passes of 16 MFMAs: pass CH multiplies the eight A blocks with column half CH.
 //   pass 0:  at its start the B fragments of column half 1 of THIS half step are read (their registers were in use until the
@@ -46,8 +49,8 @@ __device__ __forceinline__ constexpr int fr_slot(int blk) { return (PAR && blk >
 //   pass 1:  the fragments of the NEXT half step (k sub-step 1 - PAR of stage `nstage`) are read: column half 0 and the two
 //            spare-slot A blocks at its start, A blocks 0..5 each right after the last MFMA on its slot; ISSUE1: two units.
 // sched_barrier(0) after every A block pins the interleave.
-template <bool A_RC, bool B_RC, int PAR, int CH, bool READ, int ISSUE, class ISSUER>
-__device__ __forceinline__ void fr_pass(f32x4_t (&acc)[8][4], FRFrags& f, const char* stage, const char* nstage, ISSUER& is, int tid,
+template <bool A_RC, bool B_RC, int PAR, int CH, bool READ, int ISSUE, int NB, class ISSUER>
+__device__ __forceinline__ void fr_pass(f32x4_t (&acc)[NB][4], FRFrags<NB>& f, const char* stage, const char* nstage, ISSUER& is, int tid,
                                         int lane, int wr, int wc) {
     if constexpr (CH == 0) {
         f.b[1][0] = fr_bfrag<B_RC>(stage, 1, 0, PAR, wc, lane);
@@ -55,21 +58,21 @@ __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[8][4], FRFrags& f, const 
     } else if constexpr (READ) {
         f.b[0][0] = fr_bfrag<B_RC>(nstage, 0, 0, 1 - PAR, wc, lane);
         f.b[0][1] = fr_bfrag<B_RC>(nstage, 0, 1, 1 - PAR, wc, lane);
-        f.a[fr_slot<1 - PAR>(6)] = fr_afrag<A_RC>(nstage, 6, 1 - PAR, wr, lane);
-        f.a[fr_slot<1 - PAR>(7)] = fr_afrag<A_RC>(nstage, 7, 1 - PAR, wr, lane);
+        f.a[fr_slot<1 - PAR, NB>(NB - 2)] = fr_afrag<A_RC, NB>(nstage, NB - 2, 1 - PAR, wr, lane);
+        f.a[fr_slot<1 - PAR, NB>(NB - 1)] = fr_afrag<A_RC, NB>(nstage, NB - 1, 1 - PAR, wr, lane);
     }
 #ifdef FR_DBG_WAIT
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const int sl = fr_slot<PAR>(g);
+    for (int g = 0; g < NB; ++g) {
+        const int sl = fr_slot<PAR, NB>(g);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             acc[g][CH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[CH][j], f.a[sl], acc[g][CH * 2 + j], 0, 0, 0);
         if constexpr (CH == 1 && READ) {
-            if (g < 6) f.a[g] = fr_afrag<A_RC>(nstage, g, 1 - PAR, wr, lane);
+            if (g < NB - 2) f.a[g] = fr_afrag<A_RC, NB>(nstage, g, 1 - PAR, wr, lane);
         }
 #ifdef FR_DBG_WAIT
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -77,33 +80,36 @@ __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[8][4], FRFrags& f, const 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ISSUE != 0) {
             if (g == 1) { if (ISSUE == 1) is.template issue<0>(tid); else is.template issue<2>(tid); __builtin_amdgcn_sched_barrier(0); }
-            if (g == 5) { if (ISSUE == 1) is.template issue<1>(tid); else is.template issue<3>(tid); __builtin_amdgcn_sched_barrier(0); }
+            if (g == NB - 3) { if (ISSUE == 1) is.template issue<1>(tid); else is.template issue<3>(tid); __builtin_amdgcn_sched_barrier(0); }
         }
     }
 }
 
 // first half step of an item: nothing was prefetched across the epilogue
-template <bool A_RC, bool B_RC>
-__device__ __forceinline__ void fr_read_first(FRFrags& f, const char* stage, int wr, int wc, int lane) {
+template <bool A_RC, bool B_RC, int NB>
+__device__ __forceinline__ void fr_read_first(FRFrags<NB>& f, const char* stage, int wr, int wc, int lane) {
     f.b[0][0] = fr_bfrag<B_RC>(stage, 0, 0, 0, wc, lane);
     f.b[0][1] = fr_bfrag<B_RC>(stage, 0, 1, 0, wc, lane);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) f.a[g] = fr_afrag<A_RC>(stage, g, 0, wr, lane);
+    for (int g = 0; g < NB; ++g) f.a[g] = fr_afrag<A_RC, NB>(stage, g, 0, wr, lane);
 }
 
 #define FR_SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <bool A_RC, bool B_RC, int EPI, bool BVIEW>
-__global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams pk) {
-    const SmxGemmParams& p = pp_kernarg();
+template <bool A_RC, bool B_RC, int EPI, bool BVIEW, bool GRP, int MT>
+__device__ __forceinline__ void fr_kernel_body() {
+    constexpr int NB = MT / 32;          // 16-row A blocks per wave (wave tile MT/2 x 64)
+    static_assert(!GRP || !BVIEW, "grouped launches: plain operand views");
+    const SmxGemmParams& p = pp_kernarg_g<GRP>(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int ntm = (p.M + PP_BM - 1) / PP_BM, ntn = (p.N + PP_BN - 1) / PP_BN;
-    const int W = ntm * ntn * p.nbatch * p.split_k;
+    const int ntm = (p.M + MT - 1) / MT, ntn = (p.N + PP_BN - 1) / PP_BN;
+    int W = ntm * ntn * p.nbatch * p.split_k;
+    if constexpr (GRP) W = pp_group().W;
 
-    PPIssue<A_RC, B_RC, BVIEW, false> is;
-    is.dv.init(p, ntm, ntn);
+    PPIssue<A_RC, B_RC, BVIEW, GRP, MT> is;
+    is.dv.init(p, ntm, ntn, MT);
     is.g = 0;
     is.q = blockIdx.x; is.qstep = gridDim.x;
     is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
@@ -130,20 +136,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams pk) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x4_t acc[8][4];
-    FRFrags f;
+    f32x4_t acc[NB][4];
+    FRFrags<NB> f;
     int seq = 0, items = 0;
-    const bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
+    bool fast_epi = (p.tr_mode & 128) && pp_views_aligned(p);
+    int gc = 0;                 // GRP: problem of the item being computed
     for (int q = blockIdx.x; q < W; q += gridDim.x) {
         PPItem it;
-        pp_decode(pp_kernarg(), is.dv, q, it);
+        if constexpr (GRP) {
+            while (q >= pp_group().wstart[gc + 1]) ++gc;
+            const SmxGemmParams& pg = pp_kernarg_g<true>(gc);
+            PPDiv d;
+            d.init(pg, (pg.M + MT - 1) / MT, (pg.N + PP_BN - 1) / PP_BN, MT);
+            pp_decode(pg, d, q - pp_group().wstart[gc], it);
+            fast_epi = (pg.tr_mode & 128) && pp_views_aligned(pg);
+        } else {
+            pp_decode(pp_kernarg(), is.dv, q, it);
+        }
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         ++items;
         if (fast_epi && wr == 0) {          // bias slice of this item -> LDS (retired by the item's first SYNC)
-            const SmxGemmParams& pq = pp_kernarg();
+            const SmxGemmParams& pq = pp_kernarg_g<GRP>(gc);
             if (pq.bias) {
                 pp_rsrc_t br = pp_make_rsrc(pq.bias + it.zbias + it.n0);
                 br[2] = max(pq.N - it.n0, 0) * 4;
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams pk) {
             }
         }
         // the item's K tile 0 is resident: prologue barrier, or the SYNC inside the previous item's last half step
-        fr_read_first<A_RC, B_RC>(f, smem + (seq & 1) * PP_STAGE, wr, wc, lane);
+        fr_read_first<A_RC, B_RC, NB>(f, smem + (seq & 1) * PP_STAGE, wr, wc, lane);
 #ifdef FR_DBG_SYNCALL
         FR_SYNC();
 #endif
@@ -160,24 +176,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams pk) {
             const char* cur = smem + (seq & 1) * PP_STAGE;
             const char* oth = smem + ((seq & 1) ^ 1) * PP_STAGE;
             // H0 (k 0..31 of tile t): pass 0 issues the last two units of stream tile seq+1, pass 1 reads k 32..63 of tile t
-            fr_pass<A_RC, B_RC, 0, 0, true, 2>(acc, f, cur, cur, is, tid, lane, wr, wc);
+            fr_pass<A_RC, B_RC, 0, 0, true, 2, NB>(acc, f, cur, cur, is, tid, lane, wr, wc);
 #ifdef FR_DBG_SYNCALL
             FR_SYNC();
 #endif
-            fr_pass<A_RC, B_RC, 0, 1, true, 0>(acc, f, cur, cur, is, tid, lane, wr, wc);
+            fr_pass<A_RC, B_RC, 0, 1, true, 0, NB>(acc, f, cur, cur, is, tid, lane, wr, wc);
 #ifdef FR_DBG_SYNCALL
             FR_SYNC();
 #endif
             // H1 (k 32..63): pass 0; SYNC: stream tile seq+1 resident for everyone, every read of tile t done -> its stage is free;
             // pass 1 reads k 0..31 of the item's next tile and issues the first two units of stream tile seq+2 into this stage
-            fr_pass<A_RC, B_RC, 1, 0, true, 0>(acc, f, cur, oth, is, tid, lane, wr, wc);
+            fr_pass<A_RC, B_RC, 1, 0, true, 0, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
             FR_SYNC();
             // (in the item's last tile these reads fetch the next item's first fragments and are dropped: one copy of the pass)
 #ifdef FR_DBG_NOGARB
-            if (t + 1 < it.nk) fr_pass<A_RC, B_RC, 1, 1, true, 1>(acc, f, cur, oth, is, tid, lane, wr, wc);
-            else fr_pass<A_RC, B_RC, 1, 1, false, 1>(acc, f, cur, oth, is, tid, lane, wr, wc);
+            if (t + 1 < it.nk) fr_pass<A_RC, B_RC, 1, 1, true, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
+            else fr_pass<A_RC, B_RC, 1, 1, false, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
 #else
-            fr_pass<A_RC, B_RC, 1, 1, true, 1>(acc, f, cur, oth, is, tid, lane, wr, wc);
+            fr_pass<A_RC, B_RC, 1, 1, true, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
 #endif
 #ifdef FR_DBG_SYNCALL
             FR_SYNC();
@@ -185,31 +201,44 @@ __global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams pk) {
             ++seq;
         }
         if (fast_epi) {
-            pp_epilogue_fast<EPI, false>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
-                                         it.ze, lane, 0);
+            pp_epilogue_fast<EPI, GRP, NB>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
+                                       it.ze, lane, gc);
         } else {
-            pp_epilogue<false>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, 0);
+            pp_epilogue<GRP, NB>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <bool A_RC, bool B_RC, int EPI, bool BVIEW = false>
+template <bool A_RC, bool B_RC, int EPI, bool BVIEW, int MT>
+__global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(SmxGemmParams p) {
+    fr_kernel_body<A_RC, B_RC, EPI, BVIEW, false, MT>();
+}
+// grouped form (smx_gemm_group): the same body over the concatenated work lists of up to PP_MAXG problems
+template <bool A_RC, bool B_RC, int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_fr_group_kernel(SmxGemmGroup grp) {
+    fr_kernel_body<A_RC, B_RC, EPI, false, true, PP_BM>();
+}
+
+template <bool A_RC, bool B_RC, int EPI, int MT>
 static void fr_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
+    constexpr bool BVIEW = false;
     static bool attr_done[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!attr_done[dev & 15]) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_fr_kernel<A_RC, B_RC, EPI, BVIEW>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_fr_kernel<A_RC, B_RC, EPI, BVIEW, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
         attr_done[dev & 15] = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_fr_kernel<A_RC, B_RC, EPI, BVIEW>), grid, dim3(512), PP_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_fr_kernel<A_RC, B_RC, EPI, BVIEW, MT>), grid, dim3(512), PP_LDS_BYTES, stream, p);
 }
 
 int smx_gemm_pp(const SmxGemmParams& p, hipStream_t stream);   // gemm_pp.hip
 
+// tr_mode 12: 256 x 256 tiles; 13: 192 x 256 tiles (N = 768 / 2304 at 16 k rows: 252 / 756 items on 256 CUs instead of 189 / 567)
 int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
     SmxGemmParams p = pin;
+    const int mt = (p.tr_mode & 255) == 13 ? 192 : PP_BM;
     if (p.act & SMX_ACT_SAVE_GRAD) return SMX_EINVAL;
     static int ncu = 0;
     if (!ncu) {
@@ -219,7 +248,7 @@ int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
         if (ncu <= 0) ncu = 256;
         ncu &= ~7;
     }
-    const long long W = (long long)((p.M + PP_BM - 1) / PP_BM) * ((p.N + PP_BN - 1) / PP_BN) * p.nbatch * p.split_k;
+    const long long W = (long long)((p.M + mt - 1) / mt) * ((p.N + PP_BN - 1) / PP_BN) * p.nbatch * p.split_k;
     const int kst = (p.K + BK - 1) / BK, per = (kst + p.split_k - 1) / p.split_k;
     if (W >= (1 << 22) || p.M >= (1 << 22) || p.N >= (1 << 22) || p.K >= (1 << 22) || p.atomic == 1 || (p.split_k - 1) * per >= kst ||
         ((p.K & 7) && !(p.a_rc && p.b_rc))) return SMX_EINVAL;
@@ -230,7 +259,7 @@ int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
     dim3 grid((unsigned)(W < wgs ? W : wgs));
     const int epi = pp_epi_class(p);
     p.tr_mode = 8;
-#define FR_GO(AR, BR, E) { if (epi == E) p.tr_mode |= 128; fr_launch<AR, BR, E>(p, grid, stream); SMX_CHECK_LAUNCH(); }
+#define FR_GO(AR, BR, E) { if (epi == E) p.tr_mode |= 128; if (mt == 192) fr_launch<AR, BR, E, 192>(p, grid, stream); else fr_launch<AR, BR, E, PP_BM>(p, grid, stream); SMX_CHECK_LAUNCH(); }
     if (!p.a_rc && !p.b_rc) {
         if (epi == PP_EPI_ACT) FR_GO(false, false, PP_EPI_ACT)
         if (epi == PP_EPI_F32) FR_GO(false, false, PP_EPI_F32)
@@ -244,4 +273,17 @@ int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
     if (p.a_rc && p.b_rc) FR_GO(true, true, PP_EPI_F32)
     return SMX_EINVAL;
 #undef FR_GO
+}
+
+// grouped weight gradients on the free-running schedule (called by smx_gemm_group, gemm_pp.hip, when the first problem asks for tr_mode 12)
+int smx_gemm_group_fr(const SmxGemmGroup& grp, dim3 grid, hipStream_t stream) {
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_fr_group_kernel<true, true, PP_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        attr_done[dev & 15] = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_fr_group_kernel<true, true, PP_EPI_F32>), grid, dim3(512), PP_LDS_BYTES, stream, grp);
+    SMX_CHECK_LAUNCH();
 }

@@ -95,9 +95,9 @@ __device__ __forceinline__ long long pp_view_off(const SmxRowView& v, int r, flo
 // reciprocals of the work-list divisors, computed once per workgroup
 struct PPDiv {
     float r_nwg, r_pg, r_split;
-    int nwg, per_group, ntm, ntn, W, kst, per;
-    __device__ __forceinline__ void init(const SmxGemmParams& p, int ntm_, int ntn_) {
-        ntm = ntm_; ntn = ntn_;
+    int nwg, per_group, ntm, ntn, W, kst, per, bm;
+    __device__ __forceinline__ void init(const SmxGemmParams& p, int ntm_, int ntn_, int bm_ = PP_BM) {
+        ntm = ntm_; ntn = ntn_; bm = bm_;
         nwg = ntm * ntn;
         per_group = PP_GROUP * ntm;
         W = nwg * p.nbatch * p.split_k;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void pp_decode(const SmxGemmParams& p, const PPDiv& d
     const int gsz = min(d.ntn - first, PP_GROUP);                     // 1..4
     const int tm = gsz == 4 ? rem >> 2 : gsz == 2 ? rem >> 1 : gsz == 1 ? rem : pp_fdiv(rem, 3, 1.0f / 3.0f);
     const int tn = first + (rem - tm * gsz);
-    it.m0 = tm * PP_BM;
+    it.m0 = tm * d.bm;
     it.n0 = tn * PP_BN;
     const int zb = pp_fdiv(z, p.split_k, d.r_split), zs = z - zb * p.split_k;
     it.za = (long long)zb * p.batch_a;
@@ -135,7 +135,8 @@ __device__ __forceinline__ void pp_decode(const SmxGemmParams& p, const PPDiv& d
 // their 16-B chunks with pp_bswz so that the permuted fragment rows {8 (i>>2) + 4 j + (i & 3)} stay conflict-free.
 __device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
-template <bool RC, bool IS_A, bool VIEW>
+// MT: rows of the output tile (256, or 192 = two wave-row groups of 96: unit AH1 then holds 2 x 32 rows)
+template <bool RC, bool IS_A, bool VIEW, int MT = PP_BM>
 struct PPOperand {
     pp_rsrc_t rsrc;
     unsigned soff;          // scalar byte offset of the current K tile
@@ -145,8 +146,11 @@ struct PPOperand {
     int rt[1], rb[1];       // RC through a batched view (VIEW): my pass-0 k-row as (row inside batch, batch); pass 1 = +32 rows
     int rpb;                // RC + VIEW: rows per batch of the view
 
-    static __device__ __forceinline__ int grow(int h, int hr) {      // unit-local row -> tile row
-        if (IS_A) return (hr >> 6) * 128 + h * 64 + (hr & 63);
+    static __device__ __forceinline__ int grow(int h, int hr) {      // unit-local row -> tile row (-1: not part of the unit)
+        if (IS_A) {
+            if (MT == 192 && h == 1) return hr < 64 ? (hr >> 5) * 96 + 64 + (hr & 31) : -1;
+            return (hr >> 6) * (MT / 2) + h * 64 + (hr & 63);
+        }
         return (hr >> 5) * 64 + h * 32 + (hr & 31);
     }
     __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& v, int row0, int nrows, int k0, int tid) {
@@ -163,8 +167,9 @@ struct PPOperand {
                     const int hr = ps * 64 + wave * 8 + (lane >> 3);
                     const int c = (lane & 7) ^ (IS_A ? ((hr >> 1) & 7) : pp_bswz(hr));
                     kc = c * 8;
-                    const int r = row0 + grow(h, hr);
-                    voff[h][ps] = r < nrows ? (unsigned)(pp_view_off(v, r, rrpb) + c * 8) * 2u : PP_OOB;
+                    const int gr = grow(h, hr);
+                    const int r = row0 + gr;
+                    voff[h][ps] = (gr >= 0 && r < nrows) ? (unsigned)(pp_view_off(v, r, rrpb) + c * 8) * 2u : PP_OOB;
                 }
         } else {
             const int kl = wave * 4 + (lane >> 4), g16 = lane & 15;      // rc_swz(kl) is the same for both passes
@@ -172,8 +177,9 @@ struct PPOperand {
             const int hc = ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int c = row0 + grow(h, hc);
-                voff[1][h] = c < nrows ? (unsigned)c * 2u : PP_OOB;
+                const int gc = grow(h, hc);
+                const int c = row0 + gc;
+                voff[1][h] = (gc >= 0 && c < nrows) ? (unsigned)c * 2u : PP_OOB;
             }
             rpb = VIEW ? (v.rows_per_batch > 0 ? v.rows_per_batch : 0x40000000) : 0;     // plain rows: one endless batch
             if constexpr (VIEW) {
@@ -203,7 +209,7 @@ struct PPOperand {
         const int krow = wave_u * 4 + ((int)(threadIdx.x & 63) >> 4);       // RC: my k-row inside a pass
         if (!RC) {
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
+            for (int ps = 0; ps < ((IS_A && MT == 192 && H == 1) ? 1 : 2); ++ps) {      // the 64-row unit: one pass
                 unsigned vo = voff[H][ps];
                 if (tail && k0 + kc >= K) vo = PP_OOB;
                 pp_dma16(rsrc, vo, soff, lds + (ps * 64 + wave_u * 8) * 128);
@@ -228,9 +234,9 @@ struct PPOperand {
 };
 
 // Issue side of the flat unit stream: runs six units ahead of the compute side over the same (item, K tile) sequence.
-template <bool A_RC, bool B_RC, bool BVIEW, bool GRP = false>
+template <bool A_RC, bool B_RC, bool BVIEW, bool GRP = false, int MT = PP_BM>
 struct PPIssue {
-    PPOperand<A_RC, true, BVIEW && A_RC> a;    // BVIEW: the (RC, RC) instantiation whose operands go through batched views
+    PPOperand<A_RC, true, BVIEW && A_RC, MT> a;    // BVIEW: the (RC, RC) instantiation whose operands go through batched views
     PPOperand<B_RC, false, BVIEW> b;
     PPDiv dv;
     int q, qstep;
@@ -252,7 +258,7 @@ struct PPIssue {
         PPItem it;
         if constexpr (GRP) {
             PPDiv d;
-            d.init(p, (p.M + PP_BM - 1) / PP_BM, (p.N + PP_BN - 1) / PP_BN);
+            d.init(p, (p.M + MT - 1) / MT, (p.N + PP_BN - 1) / PP_BN, MT);
             pp_decode(p, d, q - pp_group().wstart[g], it);
             K = p.K;
         } else {
@@ -307,8 +313,8 @@ __device__ __forceinline__ bf16x8_t pp_bfrag(const char* unit, int r32, int j, i
 }
 
 // acc[rh*4+a][2 ch + j][r]: row mw0 + rh*64 + a*16 + (lane & 15), column nw0 + ch*32 + 8 (lane >> 4) + 4 j + r
-template <bool GRP = false>
-__device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[8][4], int mw0, int nw0, long long zc, long long zbias,
+template <bool GRP = false, int NB = 8>
+__device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[NB][4], int mw0, int nw0, long long zc, long long zbias,
                                             long long ze, int lane, int gi = 0) {
     const SmxGemmParams& p = pp_kernarg_g<GRP>(gi);
     const int i16 = lane & 15, g = lane >> 4;
@@ -332,17 +338,18 @@ __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[8][4], int mw0, int n
     // rolled over the 16 (row block, column half) pieces - ONE copy of the row epilogue in the binary; the accumulators
     // are picked by a wave-uniform switch so that every register index stays static
 #pragma clang loop unroll(disable)
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < 2 * NB; ++it) {
         float x[8], b8[8];
-#define PP_GET(A, C)                                                                                     \
+#define PP_GET(A_, C)                                                                                    \
+    constexpr int A = (A_) < NB ? (A_) : 0;                                                              \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) b8[e] = bs[C][e];                                      \
     x[0] = acc[A][2 * C][0]; x[1] = acc[A][2 * C][1]; x[2] = acc[A][2 * C][2]; x[3] = acc[A][2 * C][3];  \
     x[4] = acc[A][2 * C + 1][0]; x[5] = acc[A][2 * C + 1][1]; x[6] = acc[A][2 * C + 1][2]; x[7] = acc[A][2 * C + 1][3];
         switch (it) {
-            case 0: PP_GET(0, 0) break;  case 1: PP_GET(0, 1) break;  case 2: PP_GET(1, 0) break;  case 3: PP_GET(1, 1) break;
-            case 4: PP_GET(2, 0) break;  case 5: PP_GET(2, 1) break;  case 6: PP_GET(3, 0) break;  case 7: PP_GET(3, 1) break;
-            case 8: PP_GET(4, 0) break;  case 9: PP_GET(4, 1) break;  case 10: PP_GET(5, 0) break; case 11: PP_GET(5, 1) break;
-            case 12: PP_GET(6, 0) break; case 13: PP_GET(6, 1) break; case 14: PP_GET(7, 0) break; default: PP_GET(7, 1) break;
+            case 0: { PP_GET(0, 0) } break;  case 1: { PP_GET(0, 1) } break;  case 2: { PP_GET(1, 0) } break;  case 3: { PP_GET(1, 1) } break;
+            case 4: { PP_GET(2, 0) } break;  case 5: { PP_GET(2, 1) } break;  case 6: { PP_GET(3, 0) } break;  case 7: { PP_GET(3, 1) } break;
+            case 8: { PP_GET(4, 0) } break;  case 9: { PP_GET(4, 1) } break;  case 10: { PP_GET(5, 0) } break; case 11: { PP_GET(5, 1) } break;
+            case 12: { PP_GET(6, 0) } break; case 13: { PP_GET(6, 1) } break; case 14: { PP_GET(7, 0) } break; default: { PP_GET(7, 1) } break;
         }
 #undef PP_GET
         const int a8 = it >> 1, ch = it & 1;
@@ -367,8 +374,8 @@ __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
     return !(m & 7) && !(p.N & 7);
 }
 
-template <int EPI, bool GRP = false>
-__device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, int nw0, int n0, const char* bias_lds,
+template <int EPI, bool GRP = false, int NB = 8>
+__device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0, int nw0, int n0, const char* bias_lds,
                                                  long long zc, long long ze, int lane, int gi = 0) {
     const SmxGemmParams& p = pp_kernarg_g<GRP>(gi);
     const int i16 = lane & 15, g = lane >> 4;
@@ -393,9 +400,9 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[8][4], int mw0, 
     const float rrc = 1.0f / (float)max(p.c.rows_per_batch, 1), rre = 1.0f / (float)max(p.e.rows_per_batch, 1);
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
-    constexpr int GA = (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT) ? 2 : 4;   // row blocks per group (x 2 halves = pieces in registers at once)
+    constexpr int GA = (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || NB % 4) ? 2 : 4;   // row blocks per group (x 2 halves = pieces in registers at once)
 #pragma unroll
-    for (int grp = 0; grp < 8 / GA; ++grp) {
+    for (int grp = 0; grp < NB / GA; ++grp) {
         long long cb[GA], eb[GA];
         bool rok[GA];
         uint4 side[GA][2];

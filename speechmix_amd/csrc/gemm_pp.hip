@@ -204,10 +204,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_group_kernel(SmxGemmGroup gr
 
 template <bool A_RC, bool B_RC, int EPI, bool BVIEW = false>
 static void pp_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[16] = {};          // per device: the 160-KB LDS opt-in is a per-device function attribute
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel<A_RC, B_RC, EPI, 0, BVIEW>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        attr_done = true;
+        attr_done[dev & 15] = true;
     }
     hipLaunchKernelGGL((gemm_bf16_pp_kernel<A_RC, B_RC, EPI, 0, BVIEW>), grid, dim3(512), PP_LDS_BYTES, stream, p);
 }
@@ -285,6 +287,8 @@ int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
 
 // Up to PP_MAXG weight-gradient problems (rows-contiguous operands, fp32 slab or plain fp32 output, plain views) in ONE
 // persistent launch: their (K slice, tile) work lists are concatenated.  Declared in include/speechmix_hip.h.
+int smx_gemm_group_fr(const SmxGemmGroup& grp, dim3 grid, hipStream_t stream);     // gemm_fr.hip
+
 extern "C" int smx_gemm_group(const SmxGemmParams* probs, int count, int dtype, hipStream_t stream) {
     (void)hipGetLastError();
     if (!probs || count < 1 || count > PP_MAXG || dtype != SMX_BF16) return SMX_EINVAL;
@@ -321,10 +325,13 @@ extern "C" int smx_gemm_group(const SmxGemmParams* probs, int count, int dtype, 
     const int cap = (probs[0].tr_mode >> 16) & 0xfff;          // as in smx_gemm_pp
     const int wgs = cap > 0 && cap < ncu ? cap : ncu;
     dim3 grid((unsigned)(W < wgs ? W : wgs));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if ((probs[0].tr_mode & 255) == 12) return smx_gemm_group_fr(grp, grid, stream);       // free-running schedule
+    static bool attr_done[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_done[dev & 15]) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_pp_group_kernel<true, true, PP_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        attr_done = true;
+        attr_done[dev & 15] = true;
     }
     hipLaunchKernelGGL((gemm_bf16_pp_group_kernel<true, true, PP_EPI_F32>), grid, dim3(512), PP_LDS_BYTES, stream, grp);
     SMX_CHECK_LAUNCH();

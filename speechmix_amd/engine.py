@@ -47,7 +47,6 @@ class Engine:
         self.ep, self.lp = enc_prefix, lm_prefix
         self._persist: Dict[str, torch.Tensor] = {}
         self.last_dropped: List[int] = []
-        self._wgrad_pick: Dict[tuple, int] = {}     # tuned (kernel, K split) choice per weight-gradient shape
         self.saved = None
         rank = int(os.environ.get("RANK", "0"))         # independent draws per data-parallel rank
         self.rng = np.random.default_rng(rank)
@@ -199,8 +198,12 @@ class Engine:
             sp = ops.pp_split(No, Ko, Kred)
             if ((No + 255) // 256) * ((Ko + 255) // 256) * sp >= 96 and sp > 1:
                 cands.append((8, sp))
+                if ops.FR_MODE != "0" and not (av.rows_per_batch > 0 or bv.rows_per_batch > 0):
+                    cands.append((12, sp))
         if len(cands) > 1 and ops.PP_MODE == "1":
             cands = cands[1:]
+        if len(cands) > 1 and ops.FR_MODE == "1" and cands[-1][0] == 12:
+            cands = cands[-1:]
 
         def run(mode, split):
             if split <= 1:
@@ -215,7 +218,7 @@ class Engine:
         pick = 0
         if len(cands) > 1:
             key = ("wgrad", ops.pp_cus(), No, Ko, Kred, av.rows_per_batch > 0, bv.rows_per_batch > 0, tuple(sorted(kw)))
-            pick = self._wgrad_pick.get(key)
+            pick = ops._tuned_get(key)
             if pick is None:
                 pick = 0
                 if all(sp > 1 for _, sp in cands):          # slab launches only: re-running them changes nothing
@@ -236,10 +239,10 @@ class Engine:
                         e1.record()
                         torch.cuda.synchronize()
                         ts.append(e0.elapsed_time(e1))
-                    pick = 1 if ts[1] < 0.97 * ts[0] else 0
+                    pick = min(range(len(ts)), key=lambda i: ts[i] * (1.0 if i == 0 else 1.03))      # ties go to the 128x128 kernel
                     if ops.TUNE_LOG is not None:
-                        ops.TUNE_LOG.append((key, ts[0] / 3, ts[1] / 3, cands[pick]))
-                self._wgrad_pick[key] = pick
+                        ops.TUNE_LOG.append((key, ts[0] / 3, ts[1] / 3, cands[pick], None, None, ts[2] / 3 if len(ts) > 2 else None))
+                ops._tuned_set(key, pick)
         run(*cands[pick])
 
     def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, side_ok=True, **kw):
@@ -317,7 +320,32 @@ class Engine:
                 dst = gw
                 kw.update(atomic=2)
             probs.append((dy, x, dst, N, K, M, kw))
-        ops.gemm_group(probs, self.dt)
+        mode = 8
+        if ops.FR_MODE == "1":
+            mode = 12
+        elif ops.FR_MODE != "0":
+            key = ("wgrad_group", ops.pp_cus(), tuple((N, K, M) for _, _, _, N, K, M, _, _, _ in grp))
+            mode = ops._tuned_get(key)
+            if mode is None:
+                mode = 8
+                if len(outs) == len(probs):            # slab launches only: re-running them changes nothing
+                    ts = {}
+                    for _ in range(2):
+                        for m in (8, 12):
+                            ops.gemm_group(probs, self.dt, mode=m)
+                            torch.cuda.synchronize()
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(3):
+                                ops.gemm_group(probs, self.dt, mode=m)
+                            e1.record()
+                            torch.cuda.synchronize()
+                            ts[m] = min(ts.get(m, 1e9), e0.elapsed_time(e1) / 3)
+                    mode = 12 if ts[12] < ts[8] else 8
+                    if ops.TUNE_LOG is not None:
+                        ops.TUNE_LOG.append((key, None, ts[8], mode, None, None, ts[12]))
+                ops._tuned_set(key, mode)
+        ops.gemm_group(probs, self.dt, mode=mode)
         if outs:
             ops.reduce_slabs_many([(dst, sp, n, gw) for dst, sp, n, gw in outs], accumulate=True)
 

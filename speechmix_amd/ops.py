@@ -64,6 +64,51 @@ def _gemm_params(a, b, c, M, N, K, a_rc=False, b_rc=False, av=None, bv=None, cv=
 # SMX_GEMM_PP = auto (default) | 0 (128x128 only) | 1 (ping-pong whenever it is applicable).
 PP_MODE = os.environ.get("SMX_GEMM_PP", "auto")
 _TUNED = {}
+# Kernel picks decide the K split and with it the fp32 summation order: bf16 results are bit-reproducible across processes only
+# with the same picks.  SMX_TUNE_FILE=path loads picks at start-up and writes new ones back at exit (JSON, keys as repr
+# strings); tuner_state() / load_tuner_state() carry them between ranks (StepRunner broadcasts rank 0's).
+_TUNE_FILE = os.environ.get("SMX_TUNE_FILE", "")
+_TUNE_DIRTY = False
+
+
+def _tuned_get(key):
+    return _TUNED.get(repr(key))
+
+
+def _tuned_set(key, val):
+    global _TUNE_DIRTY
+    _TUNED[repr(key)] = val
+    _TUNE_DIRTY = True
+
+
+def tuner_state():
+    """Every pick made so far (GEMM kernel per launch key, weight-gradient candidates): {repr(key): pick}."""
+    return dict(_TUNED)
+
+
+def load_tuner_state(state):
+    _TUNED.update(state)
+
+
+def _tune_file_load():
+    if _TUNE_FILE and os.path.exists(_TUNE_FILE):
+        import json
+        with open(_TUNE_FILE) as f:
+            _TUNED.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in json.load(f).items()})
+
+
+def _tune_file_save():
+    if _TUNE_FILE and _TUNE_DIRTY:
+        import json
+        tmp = _TUNE_FILE + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(_TUNED, f, indent=0, sort_keys=True)
+        os.replace(tmp, _TUNE_FILE)
+
+
+_tune_file_load()
+import atexit as _atexit
+_atexit.register(_tune_file_save)
 _TUNE_MARGIN = float(os.environ.get("SMX_TUNE_MARGIN", "1.03"))     # a challenger must beat the 128x128 kernel by this factor
 # The ping-pong kernel needs a whole CU per workgroup (160 KB of LDS, the full register file).  A kernel running beside it
 # - RCCL's all-reduce of the gradient buckets on the side stream during backward - takes CUs away, and the displaced
@@ -111,8 +156,21 @@ def _pp_applicable(p, dtype):
     return items >= 96                     # fewer work items than that cannot occupy the chip with one workgroup per CU
 
 
+FR_MODE = os.environ.get("SMX_GEMM_FR", "auto")       # free-running 256x256 schedule (tr_mode 12, csrc/gemm_fr.hip): auto | 0 | 1
+
+
+def _fr_applicable(p, dtype):
+    """tr_mode 12 runs the ping-pong kernel's tile under the free-running schedule; instantiated for the (KC, KC), (KC, RC)
+    and (RC, RC) layouts without batched views of rows-contiguous operands (those fall back to the ping-pong kernel)."""
+    if FR_MODE == "0" or not _pp_applicable(p, dtype):
+        return False
+    if (p.a_rc and not p.b_rc) or (p.a_rc and p.a.rows_per_batch > 0) or (p.b_rc and p.b.rows_per_batch > 0):
+        return False
+    return True
+
+
 def _launch(p, dtype):
-    if (p.tr_mode & 255) == 8 and pp_cus():
+    if (p.tr_mode & 255) in (8, 12, 13) and pp_cus():
         p.tr_mode = (p.tr_mode & 0xffff) | (pp_cus() << 16)          # persistent grid cap (gemm_pp.hip)
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
 
@@ -165,6 +223,12 @@ def _choose_mode(p, dtype):
         if PP_MODE == "1":
             return 8
         cands.append(8)
+        if _fr_applicable(p, dtype):
+            if FR_MODE == "1":
+                return 12
+            cands.append(12)
+            if p.M >= 1024 and p.split_k == 1:          # 192 x 256 tiles: better quantisation of N = 768 / 2304 at 16 k rows
+                cands.append(13)
     if _half_applicable(p, dtype):
         if HALF_MODE == "1":
             return 9
@@ -177,7 +241,7 @@ def _choose_mode(p, dtype):
         return 1
     key = (tuple(cands), pp_cus(), p.a_rc, p.b_rc, p.M, p.N, p.K, p.nbatch, p.split_k, bool(p.bias), bool(p.resid), bool(p.aux_out), bool(p.aux_in),
            p.act, p.out_f32, p.atomic, p.drop_p > 0, p.a.rows_per_batch > 0, p.b.rows_per_batch > 0, p.c.rows_per_batch > 0)
-    mode = _TUNED.get(key)
+    mode = _tuned_get(key)
     if mode is None:
         # re-running the launch must not change the result: no accumulation into C, no side input aliasing the output
         safe = p.atomic == 0 and p.resid != p.C and p.aux_in != p.C and p.A != p.C and p.B != p.C
@@ -193,8 +257,8 @@ def _choose_mode(p, dtype):
                     times[m] = min(times.get(m, t), t)
             mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else _TUNE_MARGIN))      # ties go to the 128x128 kernel
             if TUNE_LOG is not None:
-                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11)))
-        _TUNED[key] = mode
+                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11), times.get(12), times.get(13)))
+        _tuned_set(key, mode)
     return mode
 
 
@@ -754,7 +818,7 @@ def _reduce_slabs(slabs, nsplit, n, stride, dst, accumulate):
                                      C.c_void_p(_ptr(dst)), int(accumulate), _stream()), "smx_reduce_slabs")
 
 
-def gemm_group(problems, dtype):
+def gemm_group(problems, dtype, mode=8):
     """ONE persistent launch of the 256x256 kernel over up to 4 weight-gradient problems (smx_gemm_group).  problems: list of
     (a, b, c, M, N, K, kw) with the arguments of `gemm` (a_rc = b_rc = True, out_f32, plain views)."""
     arr = (L.GemmParams * len(problems))()
@@ -766,13 +830,12 @@ def gemm_group(problems, dtype):
     if prof is not None:
         e0, e1 = prof.events()
         e0.record()
-    if pp_cus():
-        arr[0].tr_mode = 8 | (pp_cus() << 16)
+    arr[0].tr_mode = mode | (pp_cus() << 16)          # mode 12: free-running schedule; bits 16..: persistent grid cap
     L.check(L.lib().smx_gemm_group(arr, len(problems), dtype, _stream()), "smx_gemm_group")
     if prof is not None:
         e1.record()
         a, b, c, M, N, K, kw = problems[0]
-        prof.add((1, 1, 8), e0, e1, flops, ("group", len(problems), K, 1, kw.get("split_k", 1)))
+        prof.add((1, 1, mode), e0, e1, flops, ("group", len(problems), K, 1, kw.get("split_k", 1)))
 
 
 def reduce_slabs_many(items, accumulate=True):
