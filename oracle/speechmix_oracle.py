@@ -84,10 +84,11 @@ def handle_decoder_input_none(decoder_start_token_id: int, batch: int = 1) -> Te
 
 
 def mha(q: Tensor, k: Tensor, v: Tensor, n_heads: int, scale: float, causal: bool = False,
-        bias: Optional[Tensor] = None) -> Tensor:
-    """softmax(q k^T * scale + bias [+ causal mask]) v.  TF:integrations/sdpa_attention.py:39-130
-    and the eager twin TF:models/bart/modeling_bart.py (eager_attention_forward).  No padding
-    mask: the reference never passes one (ref:speechmix/model.py:148, 135-136)."""
+        bias: Optional[Tensor] = None, key_len: Optional[Tensor] = None) -> Tensor:
+    """softmax(q k^T * scale + bias [+ causal mask] [+ key padding mask]) v.  TF:integrations/sdpa_attention.py:39-130
+    and the eager twin TF:models/bart/modeling_bart.py (eager_attention_forward).  key_len [B]: keys at positions >=
+    key_len[b] are padding (a right-padded `attention_mask`, the reference's hook ref:speechmix/model.py:132-136; the
+    reference's own forward never passes one, ref:speechmix/model.py:148)."""
     B, Tq, D = q.shape
     Tk = k.shape[1]
     hd = D // n_heads
@@ -100,6 +101,9 @@ def mha(q: Tensor, k: Tensor, v: Tensor, n_heads: int, scale: float, causal: boo
     if causal:
         m = torch.ones(Tq, Tk, dtype=torch.bool).tril(diagonal=Tk - Tq)
         s = s.masked_fill(~m, float("-inf"))
+    if key_len is not None:
+        pad = torch.arange(Tk)[None, :] >= torch.as_tensor(key_len, dtype=torch.long)[:, None]            # [B, Tk]
+        s = s.masked_fill(pad[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
     o = p @ vh
     return o.transpose(1, 2).reshape(B, Tq, D)
@@ -156,7 +160,7 @@ def pos_conv_embed(sd, cfg, h: Tensor, prefix="encoder.pos_conv_embed.") -> Tens
     return gelu(y).transpose(1, 2)
 
 
-def w2v2_layer(sd, cfg, h: Tensor, p: str, stable: bool) -> Tensor:
+def w2v2_layer(sd, cfg, h: Tensor, p: str, stable: bool, key_len: Optional[Tensor] = None) -> Tensor:
     """TF:...wav2vec2.py:575-608 (post-LN) / 611-654 (stable LN); attention :466-548; FFN :551-572."""
     eps = cfg["layer_norm_eps"]
     nh = cfg["num_attention_heads"]
@@ -166,7 +170,7 @@ def w2v2_layer(sd, cfg, h: Tensor, p: str, stable: bool) -> Tensor:
         q = linear(x, sd, p + "attention.q_proj")
         k = linear(x, sd, p + "attention.k_proj")
         v = linear(x, sd, p + "attention.v_proj")
-        return linear(mha(q, k, v, nh, hd ** -0.5), sd, p + "attention.out_proj")
+        return linear(mha(q, k, v, nh, hd ** -0.5, key_len=key_len), sd, p + "attention.out_proj")
 
     def ffn(x):
         x = act_fn(cfg["hidden_act"])(linear(x, sd, p + "feed_forward.intermediate_dense"))
@@ -181,9 +185,19 @@ def w2v2_layer(sd, cfg, h: Tensor, p: str, stable: bool) -> Tensor:
     return h
 
 
+def feature_lengths(cfg: dict, sample_lengths) -> Tensor:
+    """TF:models/wav2vec2/modeling_wav2vec2.py:997-1036 per clip: frames that come from real (unpadded) samples."""
+    return torch.tensor([conv_out_len(int(n), cfg["conv_kernel"], cfg["conv_stride"]) for n in sample_lengths], dtype=torch.long)
+
+
 def speech_encoder(sd: Dict[str, Tensor], cfg: dict, input_values: Tensor, num_layers: Optional[int] = None,
-                   trace: Optional[dict] = None):
-    """wav2vec2 / HuBERT forward in eval mode (no dropout / layerdrop / SpecAugment).
+                   trace: Optional[dict] = None, spec_mask: Optional[Tensor] = None, layer_keep=None,
+                   frame_lengths: Optional[Tensor] = None):
+    """wav2vec2 / HuBERT forward without dropout.  Train-mode decisions are INPUTS: `spec_mask` bool [B,T] = the frames
+    SpecAugment replaces with `masked_spec_embed` (TF:models/wav2vec2/modeling_wav2vec2.py:1074-1119, after the feature
+    projection), `layer_keep` = per-layer LayerDrop keep flags (TF:...wav2vec2.py:709-723).  `frame_lengths` [B] = valid frames
+    per clip when an `attention_mask` is given (TF:...wav2vec2.py:1041-1060): padded frames are zeroed before the positional
+    convolution and masked as attention keys (TF:...wav2vec2.py:688-697, 772-781).
     TF:models/wav2vec2/modeling_wav2vec2.py:1319-1375, 667-802; TF:models/hubert/modeling_hubert.py:216-232.
     Returns (last_hidden_state [B,T,d], tuple of L+1 hidden states)."""
     eps = cfg["layer_norm_eps"]
@@ -195,6 +209,13 @@ def speech_encoder(sd: Dict[str, Tensor], cfg: dict, input_values: Tensor, num_l
     h = linear(feats, sd, "feature_projection.projection")
     if trace is not None:
         trace["feature_projection"] = h
+    if spec_mask is not None:
+        h = torch.where(torch.as_tensor(spec_mask, dtype=torch.bool)[..., None], sd["masked_spec_embed"].to(h.dtype), h)
+    key_len = None
+    if frame_lengths is not None:
+        key_len = torch.as_tensor(frame_lengths, dtype=torch.long)
+        valid = torch.arange(h.shape[1])[None, :] < key_len[:, None]
+        h = h * valid[..., None].to(h.dtype)
     h = h + pos_conv_embed(sd, cfg, h)
     if not stable:
         h = layer_norm(h, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], eps)
@@ -204,7 +225,9 @@ def speech_encoder(sd: Dict[str, Tensor], cfg: dict, input_values: Tensor, num_l
     hidden = []
     for i in range(L):
         hidden.append(h)
-        h = w2v2_layer(sd, cfg, h, f"encoder.layers.{i}.", stable)
+        if layer_keep is not None and not bool(layer_keep[i]):
+            continue
+        h = w2v2_layer(sd, cfg, h, f"encoder.layers.{i}.", stable, key_len)
     if stable:
         h = layer_norm(h, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], eps)
     hidden.append(h)
@@ -214,12 +237,12 @@ def speech_encoder(sd: Dict[str, Tensor], cfg: dict, input_values: Tensor, num_l
 # --------------------------------------------------------------------------------------------
 # seq2seq language models (text encoder + decoder + head)
 # --------------------------------------------------------------------------------------------
-def _bart_attn(sd, p, x, kv, nh, causal=False):
+def _bart_attn(sd, p, x, kv, nh, causal=False, key_len=None):
     D = x.shape[-1]
     q = linear(x, sd, p + "q_proj")
     k = linear(kv, sd, p + "k_proj")
     v = linear(kv, sd, p + "v_proj")
-    return linear(mha(q, k, v, nh, (D // nh) ** -0.5, causal=causal), sd, p + "out_proj")
+    return linear(mha(q, k, v, nh, (D // nh) ** -0.5, causal=causal, key_len=key_len), sd, p + "out_proj")
 
 
 def lm_adapter(adapters: Optional[Dict[str, Tensor]], idx: int, x: Tensor) -> Tensor:
@@ -237,7 +260,7 @@ def lm_adapter(adapters: Optional[Dict[str, Tensor]], idx: int, x: Tensor) -> Te
 
 
 def bart_like_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Tensor],
-                      decoder_input_ids: Tensor, trace: Optional[dict] = None, adapters=None):
+                      decoder_input_ids: Tensor, trace: Optional[dict] = None, adapters=None, enc_key_len=None):
     """BART (post-LN) and mBART (pre-LN + final LNs) forward, eval mode.
     TF:models/bart/modeling_bart.py:58-98 (learned positions, offset 2), 260-390 (layers), 507-549
     (encoder), 594-676 (decoder), 939-940 (head + final_logits_bias);
@@ -261,12 +284,12 @@ def bart_like_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optio
     for i in range(cfg["encoder_layers"]):
         p = f"model.encoder.layers.{i}."
         if not pre_ln:
-            h = ln(h + _bart_attn(sd, p + "self_attn.", h, h, cfg["encoder_attention_heads"]),
+            h = ln(h + _bart_attn(sd, p + "self_attn.", h, h, cfg["encoder_attention_heads"], key_len=enc_key_len),
                    p + "self_attn_layer_norm")
             h = ln(h + linear(act(linear(h, sd, p + "fc1")), sd, p + "fc2"), p + "final_layer_norm")
         else:
             x = ln(h, p + "self_attn_layer_norm")
-            h = h + _bart_attn(sd, p + "self_attn.", x, x, cfg["encoder_attention_heads"])
+            h = h + _bart_attn(sd, p + "self_attn.", x, x, cfg["encoder_attention_heads"], key_len=enc_key_len)
             h = h + linear(act(linear(ln(h, p + "final_layer_norm"), sd, p + "fc1")), sd, p + "fc2")
         h = lm_adapter(adapters, i, h)
     if pre_ln:
@@ -284,12 +307,12 @@ def bart_like_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optio
         p = f"model.decoder.layers.{i}."
         if not pre_ln:
             y = ln(y + _bart_attn(sd, p + "self_attn.", y, y, nh, causal=True), p + "self_attn_layer_norm")
-            y = ln(y + _bart_attn(sd, p + "encoder_attn.", y, enc, nh), p + "encoder_attn_layer_norm")
+            y = ln(y + _bart_attn(sd, p + "encoder_attn.", y, enc, nh, key_len=enc_key_len), p + "encoder_attn_layer_norm")
             y = ln(y + linear(act(linear(y, sd, p + "fc1")), sd, p + "fc2"), p + "final_layer_norm")
         else:
             x = ln(y, p + "self_attn_layer_norm")
             y = y + _bart_attn(sd, p + "self_attn.", x, x, nh, causal=True)
-            y = y + _bart_attn(sd, p + "encoder_attn.", ln(y, p + "encoder_attn_layer_norm"), enc, nh)
+            y = y + _bart_attn(sd, p + "encoder_attn.", ln(y, p + "encoder_attn_layer_norm"), enc, nh, key_len=enc_key_len)
             y = y + linear(act(linear(ln(y, p + "final_layer_norm"), sd, p + "fc1")), sd, p + "fc2")
         y = lm_adapter(adapters, cfg["encoder_layers"] + i, y)     # (index: both stacks of every named LM are equally deep)
     if pre_ln:
@@ -328,7 +351,7 @@ def t5_position_bias(table: Tensor, q_len: int, k_len: int, bidirectional: bool,
 
 
 def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Tensor],
-               decoder_input_ids: Tensor, trace: Optional[dict] = None, adapters=None):
+               decoder_input_ids: Tensor, trace: Optional[dict] = None, adapters=None, enc_key_len=None):
     """T5 forward, eval mode.  TF:models/t5/modeling_t5.py:50-94 (RMSNorm, FF), 176-369 (attention:
     no QK scaling, shared bucketed relative bias from block 0), 640-752 (stack), 1044-1054 (logit
     scale d_model^-0.5 when embeddings are tied)."""
@@ -340,11 +363,11 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
     act = act_fn(cfg.get("dense_act_fn", "relu"))
     emb = sd["shared.weight"]
 
-    def attn(p, x, kv, bias, causal):
+    def attn(p, x, kv, bias, causal, key_len=None):
         q = x @ sd[p + "q.weight"].t()
         k = kv @ sd[p + "k.weight"].t()
         v = kv @ sd[p + "v.weight"].t()
-        return mha(q, k, v, nh, 1.0, causal=causal, bias=bias) @ sd[p + "o.weight"].t()
+        return mha(q, k, v, nh, 1.0, causal=causal, bias=bias, key_len=key_len) @ sd[p + "o.weight"].t()
 
     def ff(p, x):
         if gated:
@@ -363,7 +386,7 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
     for i in range(cfg["num_layers"]):
         p = f"encoder.block.{i}."
         x = rms_norm(h, sd[p + "layer.0.layer_norm.weight"], eps)
-        h = h + attn(p + "layer.0.SelfAttention.", x, x, ebias, False)
+        h = h + attn(p + "layer.0.SelfAttention.", x, x, ebias, False, enc_key_len)
         h = h + ff(p + "layer.1.DenseReluDense.", rms_norm(h, sd[p + "layer.1.layer_norm.weight"], eps))
         h = lm_adapter(adapters, i, h)
     enc = rms_norm(h, sd["encoder.final_layer_norm.weight"], eps)
@@ -379,7 +402,7 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
         x = rms_norm(y, sd[p + "layer.0.layer_norm.weight"], eps)
         y = y + attn(p + "layer.0.SelfAttention.", x, x, dbias, True)
         x = rms_norm(y, sd[p + "layer.1.layer_norm.weight"], eps)
-        y = y + attn(p + "layer.1.EncDecAttention.", x, enc, None, False)
+        y = y + attn(p + "layer.1.EncDecAttention.", x, enc, None, False, enc_key_len)
         y = y + ff(p + "layer.2.DenseReluDense.", rms_norm(y, sd[p + "layer.2.layer_norm.weight"], eps))
         y = lm_adapter(adapters, cfg["num_layers"] + i, y)
     y = rms_norm(y, sd["decoder.final_layer_norm.weight"], eps)
@@ -393,12 +416,16 @@ def t5_forward(sd, cfg, inputs_embeds: Optional[Tensor], input_ids: Optional[Ten
     return y @ head.t(), enc
 
 
-def lm_forward(sd, cfg, inputs_embeds=None, input_ids=None, decoder_input_ids=None, trace=None, adapters=None):
+def lm_forward(sd, cfg, inputs_embeds=None, input_ids=None, decoder_input_ids=None, trace=None, adapters=None,
+               attention_mask=None):
+    """attention_mask [B,S] of ones then zeros (right padding): encoder keys beyond each row's length are masked in the
+    text encoder's self-attention and in the decoder's cross-attention (TF:models/bart/modeling_bart.py:741-760, 1010-1016)."""
     mt = cfg["model_type"]
+    kl = None if attention_mask is None else torch.as_tensor(attention_mask).long().sum(-1)
     if mt in ("bart", "mbart"):
-        return bart_like_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace, adapters)
+        return bart_like_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace, adapters, kl)
     if mt == "t5":
-        return t5_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace, adapters)
+        return t5_forward(sd, cfg, inputs_embeds, input_ids, decoder_input_ids, trace, adapters, kl)
     raise ValueError(mt)
 
 
@@ -457,9 +484,14 @@ def length_adapters(rest: Dict[str, Tensor], x: Tensor, downloop: int) -> Tensor
 def speechmix_eed_forward(sd: Dict[str, Tensor], enc_cfg: dict, lm_cfg: dict, input_values: Tensor,
                           labels: Optional[Tensor] = None, decoder_input_ids: Optional[Tensor] = None,
                           down_scale: int = 8, weighted_sum: bool = False, num_speech_layers: Optional[int] = None,
-                          prompt_ids: Optional[Tensor] = None, trace: Optional[dict] = None) -> dict:
+                          prompt_ids: Optional[Tensor] = None, trace: Optional[dict] = None,
+                          spec_mask: Optional[Tensor] = None, layer_keep=None, sample_lengths=None,
+                          lm_attention_mask: Optional[Tensor] = None) -> dict:
     """ref:speechmix/model.py:139-177 with HF-twin semantics where the two differ
-    (weights_sum has L+1 entries, ref:speechmix/hf_model.py:268-270, 411-423)."""
+    (weights_sum has L+1 entries, ref:speechmix/hf_model.py:268-270, 411-423).  spec_mask / layer_keep: train-mode decisions
+    handed in (see speech_encoder).  sample_lengths [B]: unpadded samples per clip = an `attention_mask` into the speech
+    encoder; lm_attention_mask [B,S] (right-padded ones): the mask the reference's `cal_loss` hook forwards to the LM
+    (ref:speechmix/model.py:132-136)."""
     enc_sd, lm_sd, rest = split_state_dict(sd)
     B = input_values.shape[0]
     if decoder_input_ids is None and labels is None:
@@ -467,7 +499,9 @@ def speechmix_eed_forward(sd: Dict[str, Tensor], enc_cfg: dict, lm_cfg: dict, in
     elif decoder_input_ids is None:
         decoder_input_ids = shift_tokens_right(labels, lm_cfg["pad_token_id"], lm_cfg["decoder_start_token_id"])
     out = {}
-    last, hidden = speech_encoder(enc_sd, enc_cfg, input_values, num_speech_layers, trace)
+    fl = feature_lengths(enc_cfg, sample_lengths) if sample_lengths is not None else None
+    last, hidden = speech_encoder(enc_sd, enc_cfg, input_values, num_speech_layers, trace, spec_mask=spec_mask,
+                                  layer_keep=layer_keep, frame_lengths=fl)
     out["encoder_last_hidden_state"] = last
     x = last
     if weighted_sum:
@@ -488,7 +522,7 @@ def speechmix_eed_forward(sd: Dict[str, Tensor], enc_cfg: dict, lm_cfg: dict, in
     out["inputs_embeds"] = x
     adapters = {k: v for k, v in rest.items() if k.startswith("adapters.")} or None          # SpeechMixAdapter
     logits, enc_last = lm_forward(lm_sd, lm_cfg, inputs_embeds=x, decoder_input_ids=decoder_input_ids, trace=trace,
-                                  adapters=adapters)
+                                  adapters=adapters, attention_mask=lm_attention_mask)
     out["lm_encoder_last_hidden"] = enc_last
     out["raw_logits"] = logits
     out["logits"] = logits.argmax(-1)

@@ -44,6 +44,7 @@ class SpeechEncoderConfig:
     mask_time_prob: float = 0.05
     mask_time_length: int = 10
     mask_time_min_masks: int = 2
+    mask_feature_prob: float = 0.0
     initializer_range: float = 0.02
 
     def to_dict(self):

@@ -34,6 +34,85 @@ def _act_id(name):
     return _ACT[name]
 
 
+class HFHostRNG:
+    """The host-side random streams HuggingFace draws from in train mode: legacy `np.random` for the SpecAugment spans
+    (TF:models/wav2vec2/modeling_wav2vec2.py:139 `np.random.rand(1)`, :183 `np.random.choice`) and torch's CPU generator for
+    LayerDrop (TF:...wav2vec2.py:712 `torch.rand([])`).  With no arguments the PROCESS-GLOBAL streams are used, so
+    `np.random.seed(k)` / `torch.manual_seed(k)` reproduce HF's indices and keep decisions bit for bit
+    (tests/test_host_logic_r3.py); `HFHostRNG.seeded(k)` owns private streams with the same draw order."""
+
+    def __init__(self, np_state=None, torch_gen=None):
+        self.np, self.tg = np_state, torch_gen
+
+    @classmethod
+    def seeded(cls, seed):
+        g = torch.Generator()
+        g.manual_seed(int(seed))
+        return cls(np.random.RandomState(int(seed)), g)
+
+    def rand(self):
+        return (self.np.rand(1) if self.np is not None else np.random.rand(1)).item()
+
+    def choice(self, n, k):
+        src = self.np if self.np is not None else np.random
+        return src.choice(np.arange(n), k, replace=False)
+
+    def layerdrop(self):
+        return (torch.rand([], generator=self.tg) if self.tg is not None else torch.rand([])).item()
+
+
+class RecordedHostRNG:
+    """Plays back recorded decisions (fixtures): `mask` = boolean [B, T] SpecAugment mask or None, `keep` = per-layer booleans."""
+
+    def __init__(self, mask=None, keep=None):
+        self.mask = None if mask is None else np.asarray(mask, dtype=bool)
+        self.keep = None if keep is None else [bool(k) for k in keep]
+        self._i = 0
+
+    def layerdrop(self):                       # < layerdrop <=> dropped
+        if self.keep is None:
+            return 2.0
+        k = self.keep[self._i % len(self.keep)]
+        self._i += 1
+        return 2.0 if k else -1.0
+
+
+def compute_mask_indices(shape, mask_prob, mask_length, rng, lengths=None, min_masks=0):
+    """TF:models/wav2vec2/modeling_wav2vec2.py:101-218 `_compute_mask_indices`, draw for draw: one `rand` for the probabilistic
+    rounding, then per batch row one `choice` of span starts without replacement over `input_length - (mask_length - 1)`
+    positions (rows shorter than the batch maximum pad their start list with their first start; an empty row uses the last
+    frame), spans clipped to the sequence end.  -> boolean [B, T]."""
+    B, T = shape
+    if mask_length < 1:
+        raise ValueError("`mask_length` has to be bigger than 0.")
+    if mask_length > T:
+        raise ValueError(f"`mask_length` has to be smaller than `sequence_length`, but got `mask_length`: {mask_length} and `sequence_length`: {T}`")
+    eps = rng.rand()
+
+    def num_spans(n):
+        k = max(int(mask_prob * n / mask_length + eps), min_masks)
+        if k * mask_length > T:
+            k = T // mask_length
+        if n - (mask_length - 1) < k:
+            k = max(n - (mask_length - 1), 0)
+        return k
+
+    lens = [T] * B if lengths is None else [int(x) for x in lengths]
+    mask = np.zeros((B, T), dtype=bool)
+    kmax = num_spans(T)
+    if kmax == 0:
+        return mask
+    for b, n in enumerate(lens):
+        k = num_spans(n)
+        starts = rng.choice(n - (mask_length - 1), k)
+        dummy = T - 1 if len(starts) == 0 else starts[0]
+        starts = np.concatenate([starts, np.ones(kmax - k, dtype=np.int32) * dummy])
+        idx = (starts[:, None] + np.arange(mask_length)[None, :]).reshape(-1)
+        idx[idx > T - 1] = T - 1
+        mask[b, idx] = True
+    return mask
+
+
 class Engine:
     def __init__(self, store: FlatStore, enc_cfg: SpeechEncoderConfig, lm_cfg: LMConfig, dtype: int,
                  num_speech_layers: int, down_scale: int, enc_prefix="encoder_model.", lm_prefix="decoder_model."):
@@ -48,8 +127,9 @@ class Engine:
         self._persist: Dict[str, torch.Tensor] = {}
         self.last_dropped: List[int] = []
         self.saved = None
-        rank = int(os.environ.get("RANK", "0"))         # independent draws per data-parallel rank
-        self.rng = np.random.default_rng(rank)
+        rank = int(os.environ.get("RANK", "0"))
+        # SpecAugment spans and LayerDrop decisions: HF's own host streams in HF's draw order (injectable: tests, replays)
+        self.host_rng = HFHostRNG()
         self.drop_rng = np.random.default_rng(0x5eed + rank)   # per-site dropout seeds (masks are regenerated in backward)
         self.stage_cb = None      # callable(stage_name): gradient ranges of that stage are final (dist.GradReducer)
         self.lm_adapters = store.has_prefix("adapters.")      # SpeechMixAdapter: bottleneck adapters behind every LM layer
@@ -842,24 +922,26 @@ class Engine:
         return dh
 
     # ------------------------------------------------------------------ SpecAugment indices (host RNG)
-    def _spec_augment_rows(self, B, T):
-        """TF:models/wav2vec2/modeling_wav2vec2.py:101-218 (_compute_mask_indices), no attention mask."""
+    def _spec_augment_rows(self, B, T, lengths=None):
+        """Flat row indices (b * T + t) of the frames HF's `_mask_hidden_states` replaces with `masked_spec_embed`
+        (TF:models/wav2vec2/modeling_wav2vec2.py:1074-1119), or None."""
         ec = self.ec
-        prob, length, mmin = ec.mask_time_prob, ec.mask_time_length, ec.mask_time_min_masks
-        if prob <= 0 or length >= T:
+        if getattr(ec, "mask_feature_prob", 0.0) > 0:
+            raise NotImplementedError("mask_feature_prob > 0 (SpecAugment along the feature axis) is not built; the reference's "
+                                      "checkpoints ship 0.0")
+        rec = getattr(self.host_rng, "mask", None)
+        if rec is not None:
+            mask = rec
+        else:
+            if ec.mask_time_prob <= 0:
+                return None
+            mask = compute_mask_indices((B, T), ec.mask_time_prob, ec.mask_time_length, self.host_rng, lengths,
+                                        ec.mask_time_min_masks)
+        self.last_spec_mask = mask
+        rows = np.flatnonzero(mask.reshape(-1))
+        if rows.size == 0:
             return None
-        eps = self.rng.random()
-        n_spans = max(int(prob * T / length + eps), mmin)
-        if n_spans * length > T:
-            n_spans = T // length
-        if n_spans <= 0:
-            return None
-        rows = []
-        for b in range(B):
-            starts = self.rng.choice(np.arange(T - (length - 1)), n_spans, replace=False)
-            idx = np.unique((starts[:, None] + np.arange(length)[None, :]).reshape(-1))
-            rows.append(idx[idx < T] + b * T)
-        return torch.from_numpy(np.concatenate(rows).astype(np.int32)).to(self.dev)
+        return torch.from_numpy(rows.astype(np.int32)).to(self.dev)
 
     # ------------------------------------------------------------------ speech encoder
     def speech_fwd(self, wave, B, N, training):
@@ -899,7 +981,8 @@ class Engine:
         sv["layers"] = []
         hidden = [x]
         for i in range(self.L):
-            if training and ec.layerdrop > 0 and self.rng.random() < ec.layerdrop:
+            # TF:...wav2vec2.py:709-723: one draw per layer (HF draws in eval mode too; only train-mode draws decide anything)
+            if training and self.host_rng.layerdrop() < ec.layerdrop:
                 sv["layers"].append(None)
                 hidden.append(x)
                 continue

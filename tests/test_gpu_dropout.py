@@ -165,7 +165,7 @@ def _train_model(case, **kw):
 
 def _loss(model, inp, seed=7):
     eng = model.engine
-    eng.rng = np.random.default_rng(seed)          # LayerDrop / SpecAugment draws
+    eng.host_rng = type(eng.host_rng).seeded(seed) if hasattr(type(eng.host_rng), 'seeded') else eng.host_rng   # LayerDrop / SpecAugment draws
     eng.drop_rng = np.random.default_rng(seed)     # dropout site seeds
     return model(inp["input_values"], labels=inp["labels"])["loss"]
 
