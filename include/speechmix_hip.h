@@ -85,6 +85,11 @@ typedef struct SmxAttnParams {
     long long q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, do_bs, do_ld;
     int B, H, Tq, Tk, D, causal; float scale; float drop_p; unsigned drop_seed;
     unsigned *mask_q, *mask_k;   /* dropout keep bits, both orientations (bf16 / head_dim 64 path; smx_attn_dropout_mask) */
+    /* optional [B] int32 on the device: keys at positions >= klen[b] are padding (a right-padded attention_mask) and get
+     * probability 0 in forward and backward; null = all Tk keys.  TF:models/wav2vec2/modeling_wav2vec2.py:688-697 (speech
+     * encoder), TF:models/bart/modeling_bart.py:741-760, 1010-1016 (text encoder self-attention, decoder cross-attention);
+     * the reference's hook ref:speechmix/model.py:132-136 forwards such a mask to the LM. */
+    const int* klen;
 } SmxAttnParams;
 /* Attention-probability dropout on the MFMA path (TF:models/wav2vec2/modeling_wav2vec2.py:533-536 nn.functional.dropout on the
  * probabilities): smx_attn_mask_words gives the sizes (32-bit words, 0/0 when no mask is needed), smx_attn_dropout_mask

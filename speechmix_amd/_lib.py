@@ -89,7 +89,7 @@ class AttnParams(C.Structure):
                 ("dv_bs", C.c_longlong), ("dv_ld", C.c_longlong), ("do_bs", C.c_longlong), ("do_ld", C.c_longlong),
                 ("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("Tk", C.c_int), ("D", C.c_int),
                 ("causal", C.c_int), ("scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint),
-                ("mask_q", C.c_void_p), ("mask_k", C.c_void_p)]
+                ("mask_q", C.c_void_p), ("mask_k", C.c_void_p), ("klen", C.c_void_p)]
 
 
 class Conv0Params(C.Structure):

@@ -32,7 +32,12 @@ struct SmxAttnParams {
     // MFMA path with dropout: the keep mask as bit matrices, written by smx_attn_dropout_mask (attention_v2.h):
     unsigned* mask_q;     // [B*H*Tq][2*ceil(Tk/64)] words, bit j of word w = key 32 w + j   (forward, dQ)
     unsigned* mask_k;     // [B*H*Tk][2*ceil(Tq/64)] words, bit j of word w = query 32 w + j (dK/dV)
+    // Optional per-clip key length (a right-padded attention mask, TF:models/wav2vec2/modeling_wav2vec2.py:688-697,
+    // TF:models/bart/modeling_bart.py:741-760; the reference's hook ref:speechmix/model.py:132-136): keys at positions >=
+    // klen[b] get probability 0 in forward and backward.  null: every key up to Tk counts.  1 <= klen[b] <= Tk.
+    const int* klen;
 };
+__device__ __forceinline__ int att_tk(const SmxAttnParams& p, int b) { return p.klen ? min(p.klen[b], p.Tk) : p.Tk; }
 // Mask index of probability (b, h, q, key): ((b H + h) Tq + q) Tkp + key with Tkp = Tk rounded up to a multiple of 4, so
 // that the 4 consecutive keys a lane holds per 16x16 score block (first key % 4 == 0) are 4 consecutive, 4-aligned
 // indices: TWO hashes (the mask function yields two elements per hash, smx_common.h) instead of four, and one row-base
@@ -70,7 +75,7 @@ __global__ void attn_fwd_simple(SmxAttnParams p) {
     float o[SIMPLE_MAXD];
     for (int d = 0; d < p.D; ++d) o[d] = 0.f;
     float m = NEG_BIG, l = 0.f;
-    const int kmax = p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk;
+    const int kmax = min(att_tk(p, b), p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk);
     for (int k = 0; k < kmax; ++k) {
         float s = 0.f;
         for (int d = 0; d < p.D; ++d) s = fmaf(Cvt<T>::ld(Q + d), Cvt<T>::ld(K + k * p.k_ld + d), s);
@@ -119,7 +124,7 @@ __global__ void attn_bwd_dq_simple(SmxAttnParams p) {
     const float lse = p.lse[idx], delta = p.delta[idx];
     float dq[SIMPLE_MAXD];
     for (int d = 0; d < p.D; ++d) dq[d] = 0.f;
-    const int kmax = p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk;
+    const int kmax = min(att_tk(p, b), p.causal ? min(p.Tk, q + (p.Tk - p.Tq) + 1) : p.Tk);
     for (int k = 0; k < kmax; ++k) {
         float s = 0.f, dp = 0.f;
         for (int d = 0; d < p.D; ++d) {
@@ -147,7 +152,7 @@ __global__ void attn_bwd_dkv_simple(SmxAttnParams p) {
     const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + h * p.D;
     float dk[SIMPLE_MAXD], dv[SIMPLE_MAXD];
     for (int d = 0; d < p.D; ++d) dk[d] = dv[d] = 0.f;
-    const int q0 = p.causal ? max(0, k - (p.Tk - p.Tq)) : 0;
+    const int q0 = k >= att_tk(p, b) ? p.Tq : (p.causal ? max(0, k - (p.Tk - p.Tq)) : 0);       // a padded key: no query sees it
     for (int q = q0; q < p.Tq; ++q) {
         float s = 0.f, dp = 0.f;
         for (int d = 0; d < p.D; ++d) {
@@ -183,6 +188,7 @@ __global__ void attn_dbias_kernel(SmxAttnParams p) {
     const float bias = p.bias ? p.bias[idx] : 0.f;
     float acc = 0.f;
     for (int b = 0; b < p.B; ++b) {
+        if (k >= att_tk(p, b)) continue;
         const T* Q = reinterpret_cast<const T*>(p.Q) + b * p.q_bs + q * p.q_ld + h * p.D;
         const T* dO = reinterpret_cast<const T*>(p.dO) + b * p.do_bs + q * p.do_ld + h * p.D;
         const T* K = reinterpret_cast<const T*>(p.K) + b * p.k_bs + k * p.k_ld + h * p.D;
@@ -750,6 +756,7 @@ extern "C" int smx_attn_dropout_mask(const SmxAttnParams* pp, hipStream_t stream
 }
 
 static int attn_check(const SmxAttnParams& p, int dtype) {
+    if (p.klen && dtype == SMX_BF16 && p.D == 64 && attn_use_v1()) return SMX_EINVAL;      // key lengths: v2 / simple kernels only
     if (p.B <= 0 || p.H <= 0 || p.Tq <= 0 || p.Tk <= 0) return SMX_EINVAL;
     if ((dtype == SMX_F32 || p.D != 64) && (p.D > SIMPLE_MAXD || (p.D & 7))) return SMX_EINVAL;
     if (p.causal && p.Tk < p.Tq) return SMX_EINVAL;

@@ -99,7 +99,7 @@ __device__ __forceinline__ float a2_and(float v, unsigned m) { return __uint_as_
 template <bool MASKED, bool BIAS, bool CAUSAL, bool DROP>
 __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* tK, const char* tV, const bf16x8_t (&qf)[2],
                                             f32x4_t (&o)[4], float& m, float& l, int k0, int q, int h, int lane, float sl2,
-                                            int coff, const uint2& mw) {
+                                            int coff, const uint2& mw, int tk) {
     const int g = lane >> 4;
     f32x4_t s[4];
     // All fragment reads of the tile are ISSUED before their first consumer: read-then-wait per MFMA made one tile a chain of
@@ -137,7 +137,7 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + t * 16 + 4 * g + r;
-                if (key >= p.Tk || (CAUSAL && key > q + coff)) s[t][r] = -INFINITY;
+                if (key >= tk || (CAUSAL && key > q + coff)) s[t][r] = -INFINITY;
             }
     }
     float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttn
     float m = NEG_BIG, l = 0.f;
     const float sl2 = p.scale * SMX_LOG2E;
     const int coff = p.Tk - p.Tq;
-    int kend = p.Tk;
-    if (CAUSAL) kend = min(p.Tk, qb0 + 64 + coff);        // keys beyond the block's last query are masked
+    const int tk = p.klen ? min(p.klen[b], p.Tk) : p.Tk;   // per-clip key length (right-padded attention mask): keys >= tk are masked
+    int kend = tk;
+    if (CAUSAL) kend = min(tk, qb0 + 64 + coff);          // keys beyond the block's last query are masked
     const uint2* mrow = nullptr;
     uint2 mw = make_uint2(0, 0), mnext = make_uint2(0, 0);
     if constexpr (DROP) {
@@ -220,9 +221,9 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttn
             if constexpr (DROP) mnext = mrow[(k0 >> 6) + 1];
         }
         // masks only where they can bite: the ragged last key tile, and tiles crossing the causal diagonal
-        const bool masked = (k0 + 64 > p.Tk) || (CAUSAL && k0 + 63 > qb0 + coff);
-        if (masked) a2_fwd_tile<true, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw);
-        else a2_fwd_tile<false, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw);
+        const bool masked = (k0 + 64 > tk) || (CAUSAL && k0 + 63 > qb0 + coff);
+        if (masked) a2_fwd_tile<true, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk);
+        else a2_fwd_tile<false, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk);
         if (more) {
             tile_store(sK[buf ^ 1], rk, tid);
             tile_store(sV[buf ^ 1], rv, tid);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttn
 template <bool MASKED, bool BIAS, bool CAUSAL, bool DROP>
 __device__ __forceinline__ void a2_dq_tile(const SmxAttnParams& p, const char* tK, const char* tV, const bf16x8_t (&qf)[2],
                                            const bf16x8_t (&dof)[2], f32x4_t (&dq)[4], float nlse2, float delta, int k0, int q,
-                                           int h, int lane, float sl2, int coff, const uint2& mw, float inv_keep) {
+                                           int h, int lane, float sl2, int coff, const uint2& mw, float inv_keep, int tk) {
     const int g = lane >> 4;
     f32x4_t ds[4];
     // fragment reads one 16-key block ahead of their MFMAs (see a2_fwd_tile)
@@ -285,7 +286,7 @@ __device__ __forceinline__ void a2_dq_tile(const SmxAttnParams& p, const char* t
             }
             float pr = fast_exp2(fmaf(sc[r], sl2, off));
             if constexpr (MASKED) {
-                if (key >= p.Tk || q >= p.Tq || (CAUSAL && key > q + coff)) pr = 0.f;
+                if (key >= tk || q >= p.Tq || (CAUSAL && key > q + coff)) pr = 0.f;
             }
             const float gp = DROP ? fmaf(a2_and(dp[r], bm[r]), inv_keep, -delta) : dp[r] - delta;
             ds[t][r] = pr * gp;
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_dq(SmxAttnP
     const float sl2 = p.scale * SMX_LOG2E;
     const float inv_keep = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const int coff = p.Tk - p.Tq;
-    int kend = p.Tk;
-    if (CAUSAL) kend = min(p.Tk, qb0 + 64 + coff);
+    const int tk = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    int kend = tk;
+    if (CAUSAL) kend = min(tk, qb0 + 64 + coff);
     const uint2* mrow = nullptr;
     uint2 mw = make_uint2(0, 0), mnext = make_uint2(0, 0);
     if constexpr (DROP) {
@@ -366,9 +368,9 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_dq(SmxAttnP
             tile_load(rv, Vp, p.v_ld, k0 + 64, p.Tk, tid);
             if constexpr (DROP) mnext = mrow[(k0 >> 6) + 1];
         }
-        const bool masked = (k0 + 64 > p.Tk) || (qb0 + 64 > p.Tq) || (CAUSAL && k0 + 63 > qb0 + coff);
-        if (masked) a2_dq_tile<true, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, dof, dq, nlse2, delta, k0, q, h, lane, sl2, coff, mw, inv_keep);
-        else a2_dq_tile<false, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, dof, dq, nlse2, delta, k0, q, h, lane, sl2, coff, mw, inv_keep);
+        const bool masked = (k0 + 64 > tk) || (qb0 + 64 > p.Tq) || (CAUSAL && k0 + 63 > qb0 + coff);
+        if (masked) a2_dq_tile<true, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, dof, dq, nlse2, delta, k0, q, h, lane, sl2, coff, mw, inv_keep, tk);
+        else a2_dq_tile<false, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, dof, dq, nlse2, delta, k0, q, h, lane, sl2, coff, mw, inv_keep, tk);
         if (more) {
             tile_store(sK[buf ^ 1], rk, tid);
             tile_store(sV[buf ^ 1], rv, tid);
@@ -393,7 +395,7 @@ template <bool MASKED, bool BIAS, bool CAUSAL, bool DROP>
 __device__ __forceinline__ void a2_dkv_tile(const SmxAttnParams& p, const char* tQ, const char* tDO, const float* sNl,
                                             const float* sDl, const bf16x8_t (&kf)[2], const bf16x8_t (&vf)[2],
                                             f32x4_t (&dk)[4], f32x4_t (&dv)[4], int q0, int key, int h, int lane, float sl2,
-                                            int coff, const uint2& mw, float inv_keep) {
+                                            int coff, const uint2& mw, float inv_keep, int tk) {
     const int g = lane >> 4;
     f32x4_t pt[4], ds[4];
     // fragment reads one 16-query block ahead of their MFMAs (see a2_fwd_tile)
@@ -438,7 +440,7 @@ __device__ __forceinline__ void a2_dkv_tile(const SmxAttnParams& p, const char* 
             }
             float pr = fast_exp2(fmaf(sc[r], sl2, off));
             if constexpr (MASKED) {
-                if (qq >= p.Tq || key >= p.Tk || (CAUSAL && key > qq + coff)) pr = 0.f;
+                if (qq >= p.Tq || key >= tk || (CAUSAL && key > qq + coff)) pr = 0.f;
             }
             if constexpr (DROP) {
                 pt[t][r] = a2_and(pr, bm[r]);                              // (x 1/(1-p): folded into dV's output scale)
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv(SmxAttnParams p) {
     const float sl2 = p.scale * SMX_LOG2E;
     const float inv_keep = DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const int coff = p.Tk - p.Tq;
+    const int tk = p.klen ? min(p.klen[b], p.Tk) : p.Tk;   // keys >= tk are padding: their probabilities are 0 -> dK = dV = 0
     int qbeg = 0;
     if (CAUSAL) qbeg = max(0, kb0 - coff) & ~63;          // queries before this see none of the block's keys
     const uint2* mrow = nullptr;
@@ -532,9 +535,9 @@ __global__ __launch_bounds__(256, 2) void attn2_dkv(SmxAttnParams p) {
             }
             if constexpr (DROP) mnext = mrow[(q0 >> 6) + 1];
         }
-        const bool masked = (q0 + 64 > p.Tq) || (kb0 + 64 > p.Tk) || (CAUSAL && kb0 + 63 > q0 + coff);
-        if (masked) a2_dkv_tile<true, BIAS, CAUSAL, DROP>(p, sQ[buf], sDO[buf], sNlse2[buf], sDelta[buf], kf, vf, dk, dv, q0, key, h, lane, sl2, coff, mw, inv_keep);
-        else a2_dkv_tile<false, BIAS, CAUSAL, DROP>(p, sQ[buf], sDO[buf], sNlse2[buf], sDelta[buf], kf, vf, dk, dv, q0, key, h, lane, sl2, coff, mw, inv_keep);
+        const bool masked = (q0 + 64 > p.Tq) || (kb0 + 64 > tk) || (CAUSAL && kb0 + 63 > q0 + coff);
+        if (masked) a2_dkv_tile<true, BIAS, CAUSAL, DROP>(p, sQ[buf], sDO[buf], sNlse2[buf], sDelta[buf], kf, vf, dk, dv, q0, key, h, lane, sl2, coff, mw, inv_keep, tk);
+        else a2_dkv_tile<false, BIAS, CAUSAL, DROP>(p, sQ[buf], sDO[buf], sNlse2[buf], sDelta[buf], kf, vf, dk, dv, q0, key, h, lane, sl2, coff, mw, inv_keep, tk);
         if (more) {
             tile_store(sQ[buf ^ 1], rq, tid);
             tile_store(sDO[buf ^ 1], rd, tid);

@@ -273,11 +273,14 @@ __global__ __launch_bounds__(256) void norm_bwd_param_kernel(SmxNormBwdParams p)
 // parameter pass alone was 1.8 % of the training step).  Same work split as the parameter kernel - a wave owns LN_PR rows,
 // all of their loads issued up front - with the row's two reductions and its dx in between; partial rows are reduced over
 // the block's four waves through LDS exactly as there (one partial row pair per block, folded later).
-template <typename T, bool ACT>
+// PR = rows per wave (a block covers 4 PR rows and leaves one partial-row set): 4 for long inputs; 2 / 1 where 16 rows per
+// block would leave the chip short of blocks (M = 7 968: 498 blocks on 256 CUs ran at 1.3 TB/s, M = 1 024: 64 blocks) and to
+// halve the registers a wave holds (more waves per SIMD to overlap the row reductions with the loads).
+template <typename T, bool ACT, int PR>
 __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p) {
     __shared__ float red[4][64][8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + w) * LN_PR;
+    const int row0 = (blockIdx.x * 4 + w) * PR;
     const float invD = 1.0f / (float)p.D;
     float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
     float dc[ACT ? 1 : LN_NCH][8];                 // column sums of the masked dx (third partial row)
@@ -298,9 +301,9 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
             if (ACT && p.beta) load8(p.beta + c, bt[j]);
         }
     }
-    float xv[LN_PR][LN_NCH][8], dv[LN_PR][LN_NCH][8], mean[LN_PR], rstd[LN_PR];
+    float xv[PR][LN_NCH][8], dv[PR][LN_NCH][8], mean[PR], rstd[PR];
 #pragma unroll
-    for (int r = 0; r < LN_PR; ++r) {
+    for (int r = 0; r < PR; ++r) {
         const int row = row0 + r;
         mean[r] = 0.f; rstd[r] = 0.f;
         if (row < p.M) {
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
         }
     }
 #pragma unroll
-    for (int r = 0; r < LN_PR; ++r) {
+    for (int r = 0; r < PR; ++r) {
         const int row = row0 + r;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -570,6 +573,15 @@ extern "C" int smx_norm_fwd(const SmxNormParams* pp, int dtype, hipStream_t stre
     SMX_CHECK_LAUNCH();
 }
 
+// rows per wave of the fused backward (one partial-row set per 4 x this many rows); the two-kernel A/B form keeps 4
+static int ln_rows_per_wave(int M) {
+    static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');
+    static const int forced = getenv("SMX_NORM_PR") ? atoi(getenv("SMX_NORM_PR")) : 0;                 // A/B switch: 1 / 2 / 4
+    if (!fuse) return LN_PR;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return M >= 32000 ? 4 : M >= 12000 ? 2 : M >= 4096 ? 4 : 1;      // measured (tools/gpu_norm_bench.py): 15 968 rows 32.9 vs 34.7 us (2 vs 4), 7 968 rows 21.3 vs 18.8, 1 024 rows 11.4 vs 12.8 (1 vs 4)
+}
+
 extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxNormBwdParams p = *pp;
@@ -583,18 +595,25 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     dim3 grid((p.M + 3) / 4);
     static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');      // A/B switch
     static const int raw_mode = getenv("SMX_NORM_RAW") ? atoi(getenv("SMX_NORM_RAW")) : -1;           // A/B switch: 0 / 1 force
+    if (p.dx_drop && !fuse) return SMX_EINVAL;          // the third output exists in the fused kernel only
     if (fuse && (p.dgamma || p.dbeta)) {
-        const int blocks = (p.M + 4 * LN_PR - 1) / (4 * LN_PR);   // workspace: blocks * 2 * D floats
+        const int pr = ln_rows_per_wave(p.M);
+        const int blocks = (p.M + 4 * pr - 1) / (4 * pr);         // workspace: blocks * 2 (3) * D floats
+#define LN_FUSED(T, A)                                                                                                  \
+    do {                                                                                                                \
+        if (pr == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<T, A, 4>), dim3(blocks), dim3(256), 0, stream, p);       \
+        else if (pr == 2) hipLaunchKernelGGL((norm_bwd_fused_kernel<T, A, 2>), dim3(blocks), dim3(256), 0, stream, p);  \
+        else hipLaunchKernelGGL((norm_bwd_fused_kernel<T, A, 1>), dim3(blocks), dim3(256), 0, stream, p);               \
+    } while (0)
         if (dtype == SMX_F32) {
-            if (act) hipLaunchKernelGGL((norm_bwd_fused_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((norm_bwd_fused_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, p);
-        } else if (!p.dx_drop && (raw_mode == 1 || (raw_mode < 0 && p.D <= 512))) {      // narrow rows: see norm_bwd_fused_raw_kernel
+            if (act) LN_FUSED(float, true); else LN_FUSED(float, false);
+        } else if (pr == LN_PR && !p.dx_drop && (raw_mode == 1 || (raw_mode < 0 && p.D <= 512))) {      // narrow rows: see norm_bwd_fused_raw_kernel
             if (act) hipLaunchKernelGGL((norm_bwd_fused_raw_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((norm_bwd_fused_raw_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
         } else {
-            if (act) hipLaunchKernelGGL((norm_bwd_fused_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((norm_bwd_fused_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
+            if (act) LN_FUSED(bf16_t, true); else LN_FUSED(bf16_t, false);
         }
+#undef LN_FUSED
         if (!p.defer_fold)
             hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((p.D + 63) / 64, blocks >= 64 ? 32 : 1), dim3(64), 0, stream,
                                p.partials, blocks, p.D, p.dgamma, p.dbeta);
@@ -623,7 +642,7 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     SMX_CHECK_LAUNCH();
 }
 
-extern "C" int smx_norm_bwd_partial_rows(int M) { return (M + 4 * LN_PR - 1) / (4 * LN_PR); }
+extern "C" int smx_norm_bwd_partial_rows(int M) { const int pr = ln_rows_per_wave(M); return (M + 4 * pr - 1) / (4 * pr); }
 
 // ABI self-description (checked by the ctypes binding against its struct mirrors)
 extern "C" int smx_sizeof_SmxNormParams(void) { return (int)sizeof(SmxNormParams); }

@@ -465,8 +465,9 @@ class Engine:
         return dict(drop=drop, gb=self.G(bname))
 
     # ------------------------------------------------------------------ attention block (self or cross)
-    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None, drop=None):
-        """names: dict(q,k,v,o -> (weight, bias|None)).  Returns (o [B*Tq, d], saved)."""
+    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None, drop=None, klen=None):
+        """names: dict(q,k,v,o -> (weight, bias|None)).  klen: int32 [B] on the device - keys >= klen[b] are padding (stays in the
+        descriptor: backward masks the same keys).  Returns (o [B*Tq, d], saved)."""
         Mq, Mk = B * Tq, B * Tk
         hd = d // H
         self_attn = kvsrc is None
@@ -475,7 +476,7 @@ class Engine:
             wqkv = self.st.cat([qn[0], kn[0], vn[0]])
             bqkv = self.st.cat([qn[1], kn[1], vn[1]], "p32") if qn[1] else None
             qkv = self.lin(x, wqkv, bqkv, Mq, 3 * d, d)
-            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop, klen=klen)
             desc.set("Q", qkv, 0, Tq * 3 * d, 3 * d)
             desc.set("K", qkv, d, Tk * 3 * d, 3 * d)
             desc.set("V", qkv, 2 * d, Tk * 3 * d, 3 * d)
@@ -485,7 +486,7 @@ class Engine:
             wkv = self.st.cat([kn[0], vn[0]])
             bkv = self.st.cat([kn[1], vn[1]], "p32") if kn[1] else None
             kv = self.lin(kvsrc, wkv, bkv, Mk, 2 * d, d)
-            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop, klen=klen)
             desc.set("Q", qkv, 0, Tq * d, d)
             desc.set("K", kv, 0, Tk * 2 * d, 2 * d)
             desc.set("V", kv, d, Tk * 2 * d, 2 * d)
@@ -593,7 +594,7 @@ class Engine:
         return dh
 
     def layer_fwd(self, x, B, T, d, H, F, nm, pre_ln, act, eps, causal=False, scale=None, enc=None, Tk=None, rms=False,
-                  bias=None, cross_bias=None, drop=None):
+                  bias=None, cross_bias=None, drop=None, klen=None, enc_klen=None):
         """One transformer layer.  nm: dict with keys attn{q,k,v,o}, ln1, [xattn, lnx], fc1, fc2, ln2.
         drop = (hidden p, attention-probability p, activation p) in training mode, else None.  Sites (identical in
         TF:models/wav2vec2/modeling_wav2vec2.py:575-654, TF:models/bart/modeling_bart.py:260-475, T5 blocks): the
@@ -606,11 +607,11 @@ class Engine:
         d_act, d_out = self._dp(pf), self._dp(ph)
         da, dxa = self._dp(pa), (self._dp(pa) if enc is not None else None)
         if not pre_ln:
-            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da)
+            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen)
             s1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x, drop=sv["d_o"])
             h, sv["ln1"] = self.ln_fwd(s1, nm["ln1"][0], nm["ln1"][1], M, d, eps)
             if enc is not None:
-                o2, sv["x"] = self.attn_fwd(h, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias, drop=dxa)
+                o2, sv["x"] = self.attn_fwd(h, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias, drop=dxa, klen=enc_klen)
                 s2 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=h,
                               drop=sv["d_xo"])
                 h, sv["lnx"] = self.ln_fwd(s2, nm["lnx"][0], nm["lnx"][1], M, d, eps)
@@ -618,11 +619,11 @@ class Engine:
             y, sv["ln2"] = self.ln_fwd(s3, nm["ln2"][0], nm["ln2"][1], M, d, eps)
         else:
             n1, sv["ln1"] = self.ln_fwd(x, nm["ln1"][0], nm["ln1"][1], M, d, eps, rms=rms)
-            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da)
+            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen)
             x1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x, drop=sv["d_o"])
             if enc is not None:
                 nx, sv["lnx"] = self.ln_fwd(x1, nm["lnx"][0], nm["lnx"][1], M, d, eps, rms=rms)
-                o2, sv["x"] = self.attn_fwd(nx, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias, drop=dxa)
+                o2, sv["x"] = self.attn_fwd(nx, enc, B, T, Tk, d, H, nm["xattn"], False, scale, cross_bias, drop=dxa, klen=enc_klen)
                 x1 = self.lin(o2, self.W(nm["xattn"]["o"][0]), self._b(nm["xattn"]["o"][1]), M, d, d, resid=x1,
                               drop=sv["d_xo"])
             n2, sv["ln2"] = self.ln_fwd(x1, nm["ln2"][0], nm["ln2"][1], M, d, eps, rms=rms)
@@ -944,7 +945,11 @@ class Engine:
         return torch.from_numpy(rows.astype(np.int32)).to(self.dev)
 
     # ------------------------------------------------------------------ speech encoder
-    def speech_fwd(self, wave, B, N, training):
+    def speech_fwd(self, wave, B, N, training, sample_lengths=None):
+        """sample_lengths: per-clip count of real (unpadded) samples = a right-padded `attention_mask` into the speech encoder.
+        HF then (TF:models/wav2vec2/modeling_wav2vec2.py:1041-1060, 1349-1358, 688-697) reduces it to frame lengths with the conv
+        arithmetic, draws the SpecAugment spans inside each clip's real frames, zeroes the padded frames ahead of the positional
+        convolution and masks them as attention keys in every layer; the CNN itself still sees the padding."""
         ec, ep = self.ec, self.ep
         d, eps = ec.hidden_size, ec.layer_norm_eps
         feat, cnn_sv = self.cnn_fwd(wave, B, N)
@@ -952,6 +957,13 @@ class Engine:
         C = ec.conv_dim[-1]
         M = B * T
         sv = dict(cnn=cnn_sv, T=T, B=B)
+        frame_len = klen = None
+        if sample_lengths is not None:
+            frame_len = [max(1, min(T, ec.frames(int(n)))) for n in sample_lengths]
+            if len(frame_len) != B:
+                raise ValueError("one length per clip")
+            klen = torch.tensor(frame_len, dtype=torch.int32, device=self.dev)
+        sv["frame_len"] = frame_len
         if ec.feat_proj_layer_norm:
             fn, sv["fp_ln"] = self.ln_fwd(feat, ep + "feature_projection.layer_norm.weight",
                                           ep + "feature_projection.layer_norm.bias", M, C, eps)
@@ -963,10 +975,16 @@ class Engine:
                      M, d, C, drop=sv["d_fp"])
         sv["mask_rows"] = None
         if training and ec.apply_spec_augment and self.has(ep + "masked_spec_embed"):
-            rows = self._spec_augment_rows(B, T)
+            rows = self._spec_augment_rows(B, T, frame_len)
             if rows is not None:
                 ops.mask_rows(h, rows, rows.numel(), self.P(ep + "masked_spec_embed"), d, self.dt)
                 sv["mask_rows"] = rows
+        sv["pad_rows"] = None
+        if frame_len is not None and min(frame_len) < T:           # "make sure padded tokens output 0" (TF:...wav2vec2.py:688-692)
+            pad = np.concatenate([np.arange(n, T) + b * T for b, n in enumerate(frame_len)]).astype(np.int32)
+            pad_rows = torch.from_numpy(pad).to(self.dev)
+            ops.mask_rows(h, pad_rows, pad_rows.numel(), self.zeros(d, dt=torch.float32), d, self.dt)
+            sv["pad_rows"] = pad_rows
         s, sv["pc"] = self.posconv_fwd(h, B, T)
         stable = ec.do_stable_layer_norm
         d_in = self._dp(ec.hidden_dropout) if training else None                # TF:...wav2vec2.py:700-703 / 786-788
@@ -987,7 +1005,7 @@ class Engine:
                 hidden.append(x)
                 continue
             x, lsv = self.layer_fwd(x, B, T, d, ec.num_attention_heads, ec.intermediate_size, self._w2v2_layer_names(i),
-                                    stable, act, eps, drop=drop)
+                                    stable, act, eps, drop=drop, klen=klen)
             sv["layers"].append(lsv)
             hidden.append(x)
         if stable:
@@ -1026,6 +1044,8 @@ class Engine:
         else:
             dx = self._dropped(dx, sv["d_in"], M * d)
         dh = self.posconv_bwd(dx, sv["pc"])
+        if sv.get("pad_rows") is not None:                         # zeroed frames pass no gradient back
+            ops.mask_rows_bwd(dh, sv["pad_rows"], sv["pad_rows"].numel(), None, d, self.dt)
         if sv["mask_rows"] is not None:
             rows = sv["mask_rows"]
             me = ep + "masked_spec_embed"
@@ -1146,7 +1166,10 @@ class Engine:
         ops.attn_bias_scatter(dbias, buckets.reshape(-1).to(torch.int32).contiguous(), self.G(tname), H, T, T,
                               self.lc.relative_attention_num_buckets)
 
-    def lm_fwd(self, inputs_embeds, input_ids, dec_ids, B, S, Ld, training):
+    def lm_fwd(self, inputs_embeds, input_ids, dec_ids, B, S, Ld, training, enc_klen=None):
+        """enc_klen: int32 [B] on the device = valid text-encoder positions per row (a right-padded `attention_mask`, the
+        reference's hook ref:speechmix/model.py:132-136): masked as keys in the text encoder's self-attention and in the
+        decoder's cross-attention (TF:models/bart/modeling_bart.py:741-760, 1010-1016)."""
         lc, lp = self.lc, self.lp
         d = lc.d_model
         t5 = lc.model_type == "t5"
@@ -1190,7 +1213,7 @@ class Engine:
         for i in range(lc.encoder_layers):
             nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
             h, lsv = self.layer_fwd(h, B, S, d, H, F, nm, pre_ln, act, eps, scale=1.0 if t5 else None, rms=t5, bias=ebias,
-                                    drop=drop)
+                                    drop=drop, klen=enc_klen)
             if self.lm_adapters:
                 h, lsv["adapter"] = self.adapter_fwd(h, i, B * S, d)
             sv["enc_layers"].append(lsv)
@@ -1219,7 +1242,7 @@ class Engine:
         for i in range(lc.decoder_layers):
             nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
             y, lsv = self.layer_fwd(y, B, Ld, d, Hd, Fd, nm, pre_ln, act, eps, causal=True, scale=1.0 if t5 else None,
-                                    enc=enc, Tk=S, rms=t5, bias=dbias, drop=drop)
+                                    enc=enc, Tk=S, rms=t5, bias=dbias, drop=drop, enc_klen=enc_klen)
             if self.lm_adapters:
                 y, lsv["adapter"] = self.adapter_fwd(y, lc.encoder_layers + i, B * Ld, d)
             sv["dec_layers"].append(lsv)
@@ -1531,11 +1554,11 @@ class Engine:
         return dh
 
     # ------------------------------------------------------------------ whole step
-    def lm_losses(self, e, dec_ids, labels, B, S, Ld, text_ids=None, training=False, want_grad=True):
+    def lm_losses(self, e, dec_ids, labels, B, S, Ld, text_ids=None, training=False, want_grad=True, enc_klen=None):
         # `training` here is the LM's own mode (dropout): SpeechMixSelf keeps the LM in eval (ref:speechmix/model.py:239)
         """LM on `inputs_embeds` e [B*S,d] (+ optional SpeechMixSelf teacher pass on text_ids) -> losses and dlogits.
         Plain: CE (ref:speechmix/model.py:132-137).  Self: CE + KLD(batchmean) + MSE (ref:speechmix/model.py:235-266)."""
-        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training)
+        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training, enc_klen=enc_klen)
         V, Vp = lsv["V"], lsv["Vp"]
         M = B * Ld
         argmax = self.new(M, dt=torch.int64)
@@ -1560,12 +1583,15 @@ class Engine:
         out.update(loss=kld + ce + mse, ce=ce, kld=kld, mse=mse, dlogits=dlogits, extra_denc=dhs)
         return out
 
-    def speech_side_fwd(self, wave, training=False, prompt_ids=None, weighted_sum=False):
+    def speech_side_fwd(self, wave, training=False, prompt_ids=None, weighted_sum=False, sample_lengths=None):
         """Everything ahead of the LM: speech encoder -> (layer-weighted sum) -> length adapters -> enc_to_dec_proj ->
-        (text-prompt embeddings prepended).  -> (inputs_embeds [B*S, d_lm], S, state for speech_side_bwd, extras)."""
+        (text-prompt embeddings prepended).  -> (inputs_embeds [B*S, d_lm], S, state for speech_side_bwd, extras).
+        sample_lengths (see speech_fwd): extras["lm_lengths"] then holds each clip's valid LM-encoder positions - the frame
+        length pushed through every Conv1d(k=2, s=2) length adapter (the conv arithmetic of TF:...wav2vec2.py:997-1036), plus
+        the prompt."""
         B, N = wave.shape
         self.mark("fwd:start")
-        x, ssv = self.speech_fwd(wave, B, N, training)
+        x, ssv = self.speech_fwd(wave, B, N, training, sample_lengths)
         self.mark("fwd:speech")
         T, d = ssv["T"], self.ec.hidden_size
         ws = None
@@ -1591,7 +1617,14 @@ class Engine:
             e = torch.cat((pe.view(1, P, dd).expand(B, P, dd), e.view(B, S, dd)), 1).contiguous().view(B * (P + S), dd)
             S = S + P
         state = dict(speech=ssv, bridge=bsv, B=B, ws=ws, P=P, prompt_ids=prompt_ids)
-        extras = dict(enc_last=x, T=T, post_adapter=bsv["post_adapter"], hidden=ssv["hidden"], sw=ws)
+        lm_lengths = None
+        if ssv.get("frame_len") is not None:
+            lm_lengths = []
+            for n in ssv["frame_len"]:
+                for _ in range(self.downloop):
+                    n = max((n - 2) // 2 + 1, 1)
+                lm_lengths.append(n + P)
+        extras = dict(enc_last=x, T=T, post_adapter=bsv["post_adapter"], hidden=ssv["hidden"], sw=ws, lm_lengths=lm_lengths)
         return e, S, state, extras
 
     def speech_side_bwd(self, de, sv):
@@ -1625,17 +1658,22 @@ class Engine:
         self._stage("frontend")
 
     def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False,
-                lm_training=None):
+                lm_training=None, sample_lengths=None, lm_mask=True):
         """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf);
         prompt_ids [P] int64: token ids of a text prompt whose embeddings are prepended to every clip
         (ref:speechmix/model.py:168-171, batch-expanded like ref:speechmix/hf_model.py:433-436)."""
         self.st.refresh_shadow()
         B = wave.shape[0]
         Ld = dec_ids.shape[1]
-        e, S, state, ex = self.speech_side_fwd(wave, training, prompt_ids, weighted_sum)
+        e, S, state, ex = self.speech_side_fwd(wave, training, prompt_ids, weighted_sum, sample_lengths)
         self.mark("fwd:bridge")
+        # sample_lengths: the speech encoder's padding mask; lm_mask: also mask the padded positions as LM-encoder keys (what HF's
+        # SpeechEncoderDecoderModel does with the reduced mask; the reference's own forward passes no mask to the LM)
+        enc_klen = None
+        if ex.get("lm_lengths") is not None and lm_mask:
+            enc_klen = torch.tensor(ex["lm_lengths"], dtype=torch.int32, device=self.dev)
         lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
-                            training=training if lm_training is None else lm_training)
+                            training=training if lm_training is None else lm_training, enc_klen=enc_klen)
         self.mark("fwd:lm")
         self.saved = dict(state, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], Ld=Ld)
         return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=ex["enc_last"],

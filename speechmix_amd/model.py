@@ -99,9 +99,10 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, wave, dec_ids, labels, training, anchor, *params):
         text_ids, prompt_ids = model._pending_text_ids, model._pending_prompt_ids
-        model._pending_text_ids = model._pending_prompt_ids = None
+        lengths = getattr(model, "_pending_lengths", None)
+        model._pending_text_ids = model._pending_prompt_ids = model._pending_lengths = None
         out = model.engine.forward(wave, dec_ids, labels, training=training, text_ids=text_ids, prompt_ids=prompt_ids,
-                                   weighted_sum=model.weighted_sum, lm_training=model._lm_training())
+                                   weighted_sum=model.weighted_sum, lm_training=model._lm_training(), sample_lengths=lengths)
         ctx.model = model
         ctx.n_params = len(params)
         model._last = out
@@ -165,7 +166,9 @@ class _LMFn(torch.autograd.Function):
         else:
             S = input_ids.shape[1]
             e2, ids = None, input_ids.reshape(-1).contiguous()
-        logits, enc, lsv = eng.lm_fwd(e2, ids, dec.reshape(-1).contiguous(), B, S, Ld, training)
+        klen = getattr(model, "_pending_enc_klen", None)
+        model._pending_enc_klen = None
+        logits, enc, lsv = eng.lm_fwd(e2, ids, dec.reshape(-1).contiguous(), B, S, Ld, training, enc_klen=klen)
         V, Vp = lsv["V"], lsv["Vp"]
         M = B * Ld
         loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
@@ -405,7 +408,21 @@ class SpeechMixEED(nn.Module):
             input_values = torch.stack([torch.as_tensor(v) for v in input_values])
         return input_values.to(self.device, torch.float32).contiguous()
 
-    def _lm_only(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None):
+    def _enc_klen(self, attention_mask, B, S):
+        """A right-padded [B, S] mask of the LM encoder's positions (the reference's hook, ref:speechmix/model.py:132-136) ->
+        int32 [B] key lengths on the device; anything else than ones followed by zeros is refused."""
+        if attention_mask is None:
+            return None
+        am = torch.as_tensor(attention_mask).to("cpu")
+        if am.shape != (B, S):
+            raise ValueError(f"attention_mask must be [{B}, {S}], got {tuple(am.shape)}")
+        n = am.long().sum(-1)
+        ref = (torch.arange(S)[None, :] < n[:, None]).to(am.dtype)
+        if not torch.equal(am, ref) or int(n.min()) < 1:
+            raise NotImplementedError("attention_mask: right-padded masks (ones, then zeros; at least one 1 per row) are supported")
+        return n.to(torch.int32).to(self.device)
+
+    def _lm_only(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None, attention_mask=None):
         """LM forward without the speech side (label creation / SpeechMixSelf text pass)."""
         self._need_engine()
         eng, lc = self.engine, self.decoder_model.config
@@ -417,11 +434,13 @@ class SpeechMixEED(nn.Module):
         if input_ids is not None:
             ids = input_ids.to(self.device)
             S = ids.shape[1]
-            logits, enc, sv = eng.lm_fwd(None, ids.reshape(-1).contiguous(), dec.reshape(-1).contiguous(), B, S, Ld, False)
+            logits, enc, sv = eng.lm_fwd(None, ids.reshape(-1).contiguous(), dec.reshape(-1).contiguous(), B, S, Ld, False,
+                                         enc_klen=self._enc_klen(attention_mask, B, S))
         else:
             emb = inputs_embeds.to(self.device, ops.torch_dtype(self.compute_dtype)).contiguous()
             S = emb.shape[1]
-            logits, enc, sv = eng.lm_fwd(emb.view(B * S, -1), None, dec.reshape(-1).contiguous(), B, S, Ld, False)
+            logits, enc, sv = eng.lm_fwd(emb.view(B * S, -1), None, dec.reshape(-1).contiguous(), B, S, Ld, False,
+                                         enc_klen=self._enc_klen(attention_mask, B, S))
         V = sv["V"]
         out = _Out(logits=logits.view(B, Ld, -1)[:, :, :V], encoder_last_hidden_state=enc.view(B, S, -1).float())
         if labels is not None:
@@ -435,14 +454,12 @@ class SpeechMixEED(nn.Module):
     def _lm_call(self, input_ids=None, inputs_embeds=None, decoder_input_ids=None, labels=None, attention_mask=None):
         """`decoder_model(...)`: autograd node when something can be differentiated, plain evaluation otherwise."""
         self._need_engine()
-        if attention_mask is not None:
-            raise NotImplementedError("attention_mask: the reference never passes one to the LM (ref:speechmix/model.py:172-173)")
         lc = self.decoder_model.config
         lm_trainable = any(p.requires_grad for p in self.decoder_model.parameters())
         emb_grad = inputs_embeds is not None and inputs_embeds.requires_grad
         if not (torch.is_grad_enabled() and (lm_trainable or emb_grad)):
             return self._lm_only(input_ids=input_ids, inputs_embeds=inputs_embeds, decoder_input_ids=decoder_input_ids,
-                                 labels=labels)
+                                 labels=labels, attention_mask=attention_mask)
         if decoder_input_ids is None and labels is not None:
             decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
         dec = decoder_input_ids.to(self.device).contiguous()
@@ -450,6 +467,8 @@ class SpeechMixEED(nn.Module):
         ids = input_ids.to(self.device).contiguous() if input_ids is not None else None
         emb = inputs_embeds.to(self.device) if inputs_embeds is not None else None
         self.engine._check_ids(lab, lc.vocab_size, "labels", allow_ignore=True)
+        S_enc = emb.shape[1] if emb is not None else ids.shape[1]
+        self._pending_enc_klen = self._enc_klen(attention_mask, dec.shape[0], S_enc)
         logits, loss = _LMFn.apply(self, emb, ids, dec, lab, self.training and self.decoder_model.training, self._anchor)
         B = dec.shape[0]
         out = _Out(logits=logits, encoder_last_hidden_state=self._last_lm_enc.view(B, -1, lc.d_model).float())
@@ -534,10 +553,20 @@ class SpeechMixEED(nn.Module):
         return am.view(B, Ld)
 
     def forward(self, input_values, input_text_prompt=None, decoder_input_ids=None, labels=None,
-                return_model_detail=False, text_input_ids=None):
+                return_model_detail=False, text_input_ids=None, attention_mask=None):
+        """ref:speechmix/model.py:139-177.  attention_mask (extension; the reference's forward has none): a right-padded
+        [B, N] sample mask, or per-clip sample counts [B].  The speech encoder then behaves like HF's wav2vec2 / HuBERT given
+        that mask (frame lengths, padded frames zeroed and masked as keys: Engine.speech_fwd) and the LM masks the padded
+        positions of `inputs_embeds` as keys, with lengths pushed through the length adapters."""
         self._need_engine()
         lc = self.decoder_model.config
         wave = self._prep_wave(input_values)
+        sample_lengths = None
+        if attention_mask is not None:
+            am = torch.as_tensor(attention_mask)
+            sample_lengths = [int(v) for v in (am.sum(-1) if am.ndim == 2 else am).tolist()]
+            if len(sample_lengths) != wave.shape[0]:
+                raise ValueError("attention_mask: one row (or one length) per clip")
         if labels is not None:
             self.engine._check_ids(labels, lc.vocab_size, "labels", allow_ignore=True)
         if decoder_input_ids is None and labels is None:
@@ -566,6 +595,8 @@ class SpeechMixEED(nn.Module):
         # single-node step computes, so they are taken on the fast path; an overridden hook is CALLED, with a differentiable
         # `inputs_embeds` from the speech-side autograd node and a differentiable `self.decoder_model(...)`.
         if not getattr(type(self).cal_loss, "_smx_builtin", False):
+            if sample_lengths is not None:
+                raise NotImplementedError("attention_mask with an overridden cal_loss: pass the LM mask to decoder_model(...) yourself")
             e = _SpeechFn.apply(self, wave, training, prompt_ids, self._anchor)
             if not torch.is_grad_enabled():
                 e = e.detach()
@@ -591,12 +622,12 @@ class SpeechMixEED(nn.Module):
             return return_dict
         if want_grad:
             params = tuple(self.store.params.values()) if self.autograd_param_inputs else ()
-            self._pending_text_ids, self._pending_prompt_ids = text, prompt_ids
+            self._pending_text_ids, self._pending_prompt_ids, self._pending_lengths = text, prompt_ids, sample_lengths
             loss = _StepFn.apply(self, wave, dec, lab, training, self._anchor, *params)
             out = self._last
         else:
             out = self.engine.forward(wave, dec, lab, training=training, text_ids=text, prompt_ids=prompt_ids,
-                                      weighted_sum=self.weighted_sum, lm_training=self._lm_training())
+                                      weighted_sum=self.weighted_sum, lm_training=self._lm_training(), sample_lengths=sample_lengths)
             loss = out["loss"].view(()) if out["loss"] is not None else None
             self.engine.saved = None
         if return_model_detail:

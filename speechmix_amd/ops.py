@@ -453,7 +453,7 @@ def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms
     sums into gb2 (the bias gradient of the Linear whose dropped output fed this norm) - one pass instead of a separate
     smx_dropout_colsum over dx."""
     ws = None
-    rows = (M + 15) // 16
+    rows = L.lib().smx_norm_bwd_partial_rows(M)      # one partial-row set per block of the fused kernel (4 / 8 / 16 rows by M)
     third = dx_drop is not None
     nrow = 3 if third else 2
     if third:
@@ -493,14 +493,18 @@ _NORM_WS = {}
 class AttnDesc:
     """Strided description of Q/K/V/O living inside fused projection buffers (element units)."""
 
-    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None, drop=None):
+    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None, drop=None, klen=None):
+        """klen: optional int32 [B] device tensor - keys at positions >= klen[b] are padding (right-padded attention mask)."""
         self.p = L.AttnParams()
         p = self.p
         p.B, p.H, p.Tq, p.Tk, p.D, p.causal, p.scale = B, H, Tq, Tk, D, int(causal), scale
         if drop is not None and drop[0] > 0:
             p.drop_p, p.drop_seed = drop
         p.bias = _ptr(bias)
-        self._keep = [bias]
+        if klen is not None:
+            assert klen.dtype == torch.int32 and klen.numel() == B and klen.is_cuda
+        p.klen = _ptr(klen)
+        self._keep = [bias, klen]
 
     def set(self, name, tensor, elem_off, batch_stride, ld):
         """name in Q K V O dO dQ dK dV"""

@@ -10,6 +10,11 @@ deterministic function of the two host random streams HF draws from:
     per-layer LayerDrop draws, hidden states, logits, loss, gradients (incl. `masked_spec_embed`)
   * eed_train_layerdrop.npz - layerdrop 0.5 / mask_time_prob 0: per-layer keep decisions (TF:...wav2vec2.py:709-723), logits,
     loss, gradients of a kept and a dropped layer
+  * lm_attention_mask.npz   - the reference's LM hook with a mask: `decoder_model(inputs_embeds=, attention_mask=, decoder_input_ids=,
+    labels=)` exactly as ref:speechmix/model.py:132-136 `cal_loss` calls it, ragged right-padded mask: logits, loss, the text
+    encoder's last hidden state, gradients wrt LM weights and wrt inputs_embeds
+  * w2v2_attention_mask.npz / hubert_attention_mask.npz - the speech encoder of HFSpeechMixEED called with a ragged sample-level
+    `attention_mask` (TF:models/wav2vec2/modeling_wav2vec2.py:1041-1060, 1349-1358, 688-697): last hidden state, all hidden states
   * mask_indices.npz        - `_compute_mask_indices` alone on a table of (shape, prob, length, min_masks, lengths, seed) cases,
     including ragged `attention_mask` lengths (integer work: the port must match bit for bit)
 Fixtures are data only: weights, inputs, outputs.
@@ -174,6 +179,68 @@ def main():
     manifest["eed_train_layerdrop"] = {"enc_cfg": G.cfg_dict(ecfg2), "lm_cfg": G.cfg_dict(lcfg), "down_scale": 2, "share_layer_ratio": 0,
                                        "route": "hf_model.HFSpeechMixEED.train()", "grads": grads2}
     print("layerdrop: keep", keep2.tolist(), "seed", seed, "loss", float(r2["loss"]), "None grads:", none_g2)
+
+    # ---------------- attention masks: the LM hook and the speech encoder ------------------------------------------
+    torch.manual_seed(77)
+    enc_dir3, ecfg3 = G.tiny_speech("w2v2", tmp)
+    lm_dir3, lcfg3 = G.tiny_lm("bart", tmp)
+    m3 = ref.HFSpeechMixEED(enc_dir3, lm_dir3, down_scale=2).eval()
+    with torch.no_grad():
+        for n, p in m3.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    B, S, d = 3, 11, lcfg3.d_model
+    emb = (torch.randn(B, S, d) * 0.5).requires_grad_(True)
+    lens = [11, 6, 2]
+    am = torch.zeros(B, S, dtype=torch.long)
+    for b, n in enumerate(lens):
+        am[b, :n] = 1
+    labels3 = torch.randint(3, 128, (B, 5)); labels3[2, -2:] = -100
+    dec3 = ref.shift_tokens_right(labels3, lcfg3.pad_token_id, lcfg3.decoder_start_token_id) if hasattr(ref, "shift_tokens_right") else None
+    m3.zero_grad()
+    kw = dict(inputs_embeds=emb, attention_mask=am, labels=labels3)
+    if dec3 is not None:
+        kw["decoder_input_ids"] = dec3
+    o3 = m3.decoder_model(**kw)                                  # what cal_loss does (ref:speechmix/model.py:135-136)
+    o3.loss.backward()
+    named3 = dict(m3.named_parameters())
+    g3 = ["decoder_model.model.encoder.layers.0.self_attn.k_proj.weight", "decoder_model.model.decoder.layers.1.encoder_attn.v_proj.weight",
+          "decoder_model.model.decoder.layers.0.encoder_attn.q_proj.bias", "decoder_model.model.shared.weight",
+          "decoder_model.model.encoder.layers.1.fc1.weight"]
+    np.savez_compressed(f"{OUT}/lm_attention_mask.npz", inputs_embeds=emb.detach().numpy(), attention_mask=am.numpy(), labels=labels3.numpy(),
+                        **{"w::" + k: v for k, v in G.to_np(m3.state_dict()).items()},
+                        **{"o::raw_logits": o3.logits.detach().numpy(), "o::loss": o3.loss.detach().numpy(),
+                           "o::lm_encoder_last_hidden": o3.encoder_last_hidden_state.detach().numpy(),
+                           "o::grad::inputs_embeds": emb.grad.numpy()},
+                        **{"o::grad::" + k: named3[k].grad.numpy() for k in g3})
+    manifest["lm_attention_mask"] = {"enc_cfg": G.cfg_dict(ecfg3), "lm_cfg": G.cfg_dict(lcfg3), "down_scale": 2, "share_layer_ratio": 0,
+                                     "route": "hf_model.HFSpeechMixEED.decoder_model(inputs_embeds, attention_mask)"}
+    print("lm mask loss", float(o3.loss))
+
+    for kind in ("w2v2", "hubert"):
+        ed, ec_ = G.tiny_speech(kind, tmp)
+        ld, lc_ = G.tiny_lm("bart", tmp)
+        mm = ref.HFSpeechMixEED(ed, ld, down_scale=2).eval()
+        with torch.no_grad():
+            for n, p in mm.named_parameters():
+                if p.ndim == 1:
+                    p.add_(torch.randn_like(p) * 0.05)
+        nsamp = [8000, 5200, 2400]
+        xw = torch.zeros(3, 8000)
+        sm = torch.zeros(3, 8000, dtype=torch.long)
+        for b, n in enumerate(nsamp):
+            xw[b, :n] = torch.randn(n) * 0.1
+            sm[b, :n] = 1
+        with torch.no_grad():
+            eo = mm.encoder_model(xw, attention_mask=sm, output_hidden_states=True)
+        np.savez_compressed(f"{OUT}/{kind}_attention_mask.npz", input_values=xw.numpy(), attention_mask=sm.numpy(),
+                            sample_lengths=np.array(nsamp, dtype=np.int64),
+                            **{"w::" + k: v for k, v in G.to_np(mm.state_dict()).items()},
+                            **{"o::encoder_last_hidden_state": eo.last_hidden_state.numpy(),
+                               "o::hidden_states": torch.stack(eo.hidden_states, 0).numpy()})
+        manifest[f"{kind}_attention_mask"] = {"enc_cfg": G.cfg_dict(ec_), "lm_cfg": G.cfg_dict(lc_), "down_scale": 2, "share_layer_ratio": 0,
+                                              "route": "hf_model.HFSpeechMixEED.encoder_model(input_values, attention_mask)"}
+        print(kind, "masked encoder out", tuple(eo.last_hidden_state.shape))
 
     # ---------------- _compute_mask_indices table ----------------------------------------------------------------
     import transformers.models.wav2vec2.modeling_wav2vec2 as W

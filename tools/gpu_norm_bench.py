@@ -6,7 +6,7 @@ import torch
 from speechmix_amd import ops
 from tools.gpu_check_pp import bench
 dev = torch.device("cuda:0")
-for M, D, res, act in ((15968, 768, True, 0), (7968, 768, True, 0), (15968, 1024, True, 0), (511968, 512, False, 0), (511968, 512, False, 1), (255968, 512, False, 1)):
+for M, D, res, act in ((15968, 768, True, 0), (7968, 768, True, 0), (1024, 768, True, 0), (15968, 1024, True, 0), (511968, 512, False, 0), (511968, 512, False, 1), (255968, 512, False, 1)):
     g = torch.Generator(device="cpu").manual_seed(0)
     x32 = torch.randn(M, D, generator=g)
     x = x32.to(dev).bfloat16(); dy = torch.randn(M, D, generator=g).to(dev).bfloat16()
