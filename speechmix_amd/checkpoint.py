@@ -89,13 +89,26 @@ def read_state_file(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    sd = torch.load(path, map_location="cpu", weights_only=True)
-    if isinstance(sd, dict) and isinstance(sd.get("model"), dict):
-        inner = sd["model"]                      # fairseq checkpoints nest the weights under "model" (next to cfg / args)
-        if inner and all(torch.is_tensor(v) for v in inner.values()):
-            sd = inner
-    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
-        sd = sd["state_dict"]
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as first:
+        # real fairseq .pt files keep an argparse.Namespace (`args`) next to the weights: allow exactly that class, nothing else
+        import argparse
+        try:
+            with torch.serialization.safe_globals([argparse.Namespace]):
+                sd = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:
+            raise RuntimeError(f"{path}: not loadable with weights_only=True (objects beyond tensors / argparse.Namespace inside); "
+                               f"convert it first, e.g. torch.save({{'model': ckpt['model']}}, ...) in a trusted environment") from first
+    # where the weights sit: fairseq nests them under "model" (next to cfg / args / task_state), s3prl-converted upstream
+    # checkpoints (what the reference's s3prl.hub.wav2vec2() / hubert_large_ll60k() download) under "model_weight" (next to
+    # task_cfg / model_cfg), lightning-style files under "state_dict"
+    for key in ("model", "model_weight", "state_dict"):
+        if isinstance(sd, dict) and isinstance(sd.get(key), dict):
+            inner = sd[key]
+            if inner and all(torch.is_tensor(v) for v in inner.values()):
+                sd = inner
+                break
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}
 
 
@@ -116,7 +129,7 @@ def read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
             for shard in files:
                 out.update(read_state_file(os.path.join(path, shard)))
             return out
-    return {}
+    raise FileNotFoundError(f"{path}: no model.safetensors / pytorch_model.bin (or their sharded indexes) in this directory")
 
 
 def load_backbone(tree: torch.nn.Module, ckpt: str) -> Dict[str, list]:
@@ -136,8 +149,16 @@ def load_backbone(tree: torch.nn.Module, ckpt: str) -> Dict[str, list]:
                 break
         else:
             unexpected.append(k)
+    if not fixed:
+        raise RuntimeError(f"{ckpt}: none of its {len(sd)} tensors matches a parameter of {type(tree).__name__} by name and shape "
+                           f"(first keys: {sorted(sd)[:3]}) - refusing to train from random initialisation silently")
     res = tree.load_state_dict(fixed, strict=False)
-    return {"loaded": sorted(fixed), "missing": list(res.missing_keys), "unexpected": unexpected}
+    missing = list(res.missing_keys)
+    if len(missing) > len(own) // 2:
+        import warnings
+        warnings.warn(f"{ckpt}: only {len(fixed)} of {len(own)} tensors of {type(tree).__name__} were found "
+                      f"(missing e.g. {missing[:3]}); the rest keep their initialisation")
+    return {"loaded": sorted(fixed), "missing": missing, "unexpected": unexpected}
 
 
 def convert_speechmix_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

@@ -83,10 +83,16 @@ def length_grouped_indices(lengths, batch_size, mega_batch_mult=None, generator=
 
 
 def bucketed_batches(dataset, collator, batch_size, lengths=None, group_by_length=True, generator=None, drop_last=False,
-                     rank=0, world=1):
+                     rank=0, world=1, seed=0, epoch=0):
     """Collated batches of one epoch for this rank: length-grouped order (or a plain permutation), cut into global batches
-    of `batch_size * world` clips of which rank r takes the r-th slice (data parallel: each clip is independent)."""
+    of `batch_size * world` clips of which rank r takes every world-th clip (`idx[rank::world]`, as HF's
+    DistributedLengthGroupedSampler does: a global batch is sorted by length, so a contiguous split would hand rank 0 the
+    longest clips of every step and make every step wait for it).  With world > 1 every rank must cut the SAME permutation:
+    without an explicit generator one is derived from (seed, epoch), never from the rank's own global RNG."""
     n = len(dataset)
+    if generator is None and world > 1:
+        generator = torch.Generator()
+        generator.manual_seed(int(seed) * 1000003 + int(epoch))
     if lengths is None:
         lengths = [len(dataset[i]["input_values"]) for i in range(n)]
     order = length_grouped_indices(lengths, batch_size * world, generator=generator) if group_by_length \
@@ -96,7 +102,7 @@ def bucketed_batches(dataset, collator, batch_size, lengths=None, group_by_lengt
         idx = order[i:i + gb]
         if len(idx) < gb and (drop_last or world > 1):
             break
-        mine = idx[rank * batch_size:(rank + 1) * batch_size]
+        mine = idx[rank::world]
         yield collator([dataset[j] for j in mine])
 
 
@@ -107,10 +113,10 @@ class DevicePrefetcher:
 
     @classmethod
     def from_dataset(cls, dataset, collator, batch_size, device, lengths=None, group_by_length=True, generator=None,
-                     rank=0, world=1):
+                     rank=0, world=1, seed=0, epoch=0):
         """Length-bucketed epoch (see `bucketed_batches`) behind the prefetcher."""
         return cls(bucketed_batches(dataset, collator, batch_size, lengths, group_by_length, generator, rank=rank,
-                                    world=world), device)
+                                    world=world, seed=seed, epoch=epoch), device)
 
     def __init__(self, batches: Iterable[Dict[str, torch.Tensor]], device):
         self.it, self.device = iter(batches), torch.device(device)

@@ -448,7 +448,7 @@ class Engine:
         train = self.tr(wname)
         extra = {}
         if (fuse is not None and train and self.folds is not None and act == ACT_NONE and not (D & 7)
-                and os.environ.get("SMX_FUSE_LN_DROPCOL") != "0"):
+                and os.environ.get("SMX_FUSE_LN_DROPCOL") != "0" and os.environ.get("SMX_NORM_FUSED") != "0"):
             fuse["out"] = self.new(M, D)
             extra = dict(drop2=fuse["drop"], dx_drop=fuse["out"], gb2=fuse["gb"])
         ops.norm_bwd(dy, x, dx, self.P(wname), self.P(bname) if bname else None, mean, rstd,

@@ -455,6 +455,10 @@ class SpeechMixEED(nn.Module):
         """`decoder_model(...)`: autograd node when something can be differentiated, plain evaluation otherwise."""
         self._need_engine()
         lc = self.decoder_model.config
+        if not getattr(self, "_in_forward", False):
+            # a stand-alone `decoder_model(...)` / `cal_loss(...)` call (text-only LM loops): its own step, so that the first
+            # backward node after an `optimizer.zero_grad()` zeroes the flat gradient instead of adding to the last call's
+            self._step_token += 1
         lm_trainable = any(p.requires_grad for p in self.decoder_model.parameters())
         emb_grad = inputs_embeds is not None and inputs_embeds.requires_grad
         if not (torch.is_grad_enabled() and (lm_trainable or emb_grad)):
@@ -603,7 +607,11 @@ class SpeechMixEED(nn.Module):
             kw = dict(inputs_embeds=e, decoder_input_ids=dec, labels=lab)
             if self._uses_text_ids:
                 kw["text_input_ids"] = text
-            outputs = self.cal_loss(**kw)
+            self._in_forward = True
+            try:
+                outputs = self.cal_loss(**kw)
+            finally:
+                self._in_forward = False
             sp = self._last_speech
             T, S = sp["T"], sp["S"]
             if return_model_detail:

@@ -205,3 +205,25 @@ def test_attention_kernels_mask_padded_keys_per_clip(dtype, D, tol, Tq, Tk, caus
         e = _err(got, want) / max(want.abs().max().item(), 1e-6)
         print(f"[attn klen {dtype} D{D} Tq{Tq} Tk{Tk} c{int(causal)}] {name} rel err {e:.3e}")
         assert e < tol, (name, e)
+
+
+def test_standalone_lm_loop_zeroes_the_flat_gradient_between_iterations():
+    """Round-2 advisor finding: consecutive `decoder_model(...).loss.backward()` + `zero_grad()` iterations outside forward()
+    (a text-only LM loop) each carry their own step token, so the second iteration does not add to the first one's gradient."""
+    model, inp, gold, m = _build("lm_attention_mask", "fp32")
+    emb = inp["inputs_embeds"].to(model.device)
+    key = "decoder_model.model.decoder.layers.1.encoder_attn.v_proj.weight"
+    grads = []
+    for it in range(3):
+        model.zero_grad(set_to_none=True)
+        out = model.decoder_model(inputs_embeds=emb, attention_mask=inp["attention_mask"], labels=inp["labels"])
+        out.loss.backward()
+        grads.append(dict(model.named_parameters())[key].grad.detach().float().cpu().clone())
+    for g in grads:
+        assert _err(g, gold["grad::" + key]) <= 3e-3 * gold["grad::" + key].abs().max().item()
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
+    # and without zero_grad the gradients accumulate, as torch's do
+    out = model.decoder_model(inputs_embeds=emb, attention_mask=inp["attention_mask"], labels=inp["labels"])
+    out.loss.backward()
+    acc = dict(model.named_parameters())[key].grad.detach().float().cpu()
+    assert _err(acc, 2 * gold["grad::" + key]) <= 6e-3 * gold["grad::" + key].abs().max().item()
