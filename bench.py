@@ -39,13 +39,27 @@ def synth_batch(B, vocab, rank, device):
     return wave.to(device), labels.to(device)
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle (CPU port of the reference path) fwd+bwd on one 10 s clip; audio-s/s on this host's cores."""
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(seconds_budget=28.0):
+    """Oracle (CPU port of the reference path) on this host's cores, bounded to ~30 s of CPU work:
+    B = 1 forward+backward (the headline `value`), forward-only, the full train step including the reference's optimizer
+    (Adafactor, ref:train.py:298), and a B = 8 leg, with the CPU model string."""
     from oracle import speechmix_oracle as O
     from speechmix_amd.configs import LMConfig, SpeechEncoderConfig
     from speechmix_amd.params import build_tree, init_lm, init_speech_encoder, spec_lm, spec_speech_encoder
-    # Bounded: the oracle is an eager PyTorch-CPU program; beyond ~16 threads its small ops only contend (a 256-thread
-    # run on the GPU box's host took 434 s per clip), so cap the pool and stop after the time budget.
+    # The oracle is an eager PyTorch-CPU program; beyond ~16 threads its small ops only contend (a 256-thread run on the GPU
+    # box's host took 434 s per clip), so the pool is capped - `cores` says what was used, `cores_available` what the host has.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -66,37 +80,94 @@ def cpu_baseline(seconds_budget=20.0):
     sd["enc_to_dec_proj.bias"] = torch.zeros(lc.d_model)
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()
               and not k.endswith(("embed_tokens.weight", "lm_head.weight"))}
-    wave, labels = synth_batch(1, lc.vocab_size, 0, "cpu")
+    wave8, labels8 = synth_batch(8, lc.vocab_size, 0, "cpu")
+    wave, labels = wave8[:1], labels8[:1]
+    t_begin = time.perf_counter()
 
-    def one(w):
+    def one(w, lab, keep_grads=False):
         t0 = time.perf_counter()
-        out = O.speechmix_eed_forward(leaves, ec.to_dict(), lc.to_dict(), w, labels=labels, down_scale=2)
+        out = O.speechmix_eed_forward(leaves, ec.to_dict(), lc.to_dict(), w, labels=lab, down_scale=2)
         out["loss"].backward()
-        for v in leaves.values():
-            v.grad = None
+        if not keep_grads:
+            for v in leaves.values():
+                v.grad = None
         return time.perf_counter() - t0
 
-    def fwd_only(w):
+    def fwd_only(w, lab):
         t0 = time.perf_counter()
         with torch.no_grad():
-            O.speechmix_eed_forward(leaves, ec.to_dict(), lc.to_dict(), w, labels=labels, down_scale=2)
+            O.speechmix_eed_forward(leaves, ec.to_dict(), lc.to_dict(), w, labels=lab, down_scale=2)
         return time.perf_counter() - t0
 
-    one(wave[:, :16000])                       # warm-up on a 1 s clip (allocator, thread pool)
-    t1 = one(wave[:, :16000])
-    if t1 * 10 > seconds_budget:               # host too slow for even one full clip inside the budget: report the 1 s sample
-        return {"value": round(1.0 / t1, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-                "sample": "1 clip x 1 s (10 s clip would exceed the time budget), fwd+bwd fp32 (no optimizer), 1 run after warm-up"}
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 5 and (not times or time.perf_counter() - t_start + times[-1] < seconds_budget):
-        times.append(one(wave))
-    t = sorted(times)[len(times) // 2]
-    ft = sorted(fwd_only(wave) for _ in range(3))[1]          # forward-only leg
-    return {"value": round(CLIP_SECONDS / t, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": f"1 clip x 10 s, fwd+bwd fp32 (no optimizer), median of {len(times)} after a 1 s warm-up clip",
-            "forward_only_value": round(CLIP_SECONDS / ft, 3),
-            "forward_only_sample": "same clip, forward only (no_grad), median of 3"}
+    one(wave[:, :16000], labels)                       # warm-up on a 1 s clip (allocator, thread pool)
+    t1 = one(wave[:, :16000], labels)
+    base = {"unit": "audio-s/s", "cores": threads, "cores_available": avail, "cpu": cpu_model_string(), "kind": "port"}
+    if t1 * 10 > seconds_budget / 2:           # host too slow for even one full clip inside the budget: report the 1 s sample
+        return dict(base, value=round(1.0 / t1, 3),
+                    sample="1 clip x 1 s (a 10 s clip would exceed the time budget), fwd+bwd fp32 (no optimizer), 1 run after warm-up")
+    times = [one(wave, labels) for _ in range(3)]
+    t = sorted(times)[1]
+    ft = sorted(fwd_only(wave, labels) for _ in range(2))[0]          # forward-only leg
+    out = dict(base, value=round(CLIP_SECONDS / t, 3),
+               sample="1 clip x 10 s, fwd+bwd fp32 (no optimizer), median of 3 after a 1 s warm-up clip",
+               forward_only_value=round(CLIP_SECONDS / ft, 3), forward_only_sample="same clip, forward only (no_grad), best of 2")
+    # full train step: fwd + bwd + the reference's optimizer (Adafactor over every trainable tensor, oracle restatement)
+    if time.perf_counter() - t_begin + t * 1.5 < seconds_budget:
+        tb = one(wave, labels, keep_grads=True)
+        t0 = time.perf_counter()
+        state = {}
+        with torch.no_grad():
+            for k, v in leaves.items():
+                if v.grad is not None:
+                    O.adafactor_step(v, v.grad, state.setdefault(k, {}), 5e-4)
+        tu = time.perf_counter() - t0
+        for v in leaves.values():
+            v.grad = None
+        out.update(train_step_value=round(CLIP_SECONDS / (tb + tu), 3),
+                   train_step_sample=f"same clip, fwd+bwd ({tb:.2f} s) + Adafactor update of all parameters ({tu:.2f} s), 1 run")
+    # B = 8: one forward-only and, if the budget allows, one forward+backward run
+    if time.perf_counter() - t_begin + 8 * ft < seconds_budget:
+        f8 = fwd_only(wave8, labels8)
+        out.update(b8_forward_only_value=round(8 * CLIP_SECONDS / f8, 3), b8_sample="8 clips x 10 s, 1 run each leg")
+        if time.perf_counter() - t_begin + 8 * t < seconds_budget + 6:
+            t8 = one(wave8, labels8)
+            out["b8_value"] = round(8 * CLIP_SECONDS / t8, 3)
+    out["cpu_seconds_spent"] = round(time.perf_counter() - t_begin, 1)
+    return out
+
+
+def measured_peaks(device):
+    """This box's MFMA and HBM peaks from the library's probe kernels (bench line: `peaks_measured`)."""
+    import ctypes as C
+    from speechmix_amd import _lib as L
+    lib = L.lib()
+    lib.smx_probe_mfma.restype = C.c_double
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outb = torch.zeros(256 * 8 * 256, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(3):
+        lib.smx_probe_mfma(C.c_void_p(outb.data_ptr()), 512, 200, st)
+        e0.record()
+        fl = lib.smx_probe_mfma(C.c_void_p(outb.data_ptr()), 512, 2000, st)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, fl / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    bw = 0.0
+    for _ in range(3):
+        lib.smx_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_longlong(n), st)
+        e0.record()
+        for _ in range(4):
+            lib.smx_probe_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_longlong(n), st)
+        e1.record()
+        torch.cuda.synchronize()
+        bw = max(bw, 4 * 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return {"mfma_bf16_tflops": round(best, 1), "mfma_probe": "v_mfma_f32_32x32x16_bf16 loop, 8 waves/CU, non-zero operands",
+            "hbm_copy_GBps": round(bw, 1), "hbm_probe": "1 GiB 16-B/lane copy, read + write bytes",
+            "datasheet": {"mfma_bf16_tflops": MFMA_BF16_PEAK_TFLOPS, "hbm_GBps": HBM_PEAK_GBPS}}
 
 
 def spawn_ranks(n, argv):
@@ -250,9 +321,8 @@ def main():
                                 "flops_per_launch": round(d["flops"] / d["launches"]),
                                 "timing": "HIP events around every launch, K identical steps right after the timed pass"}
             # HBM-side bytes per launch of that kernel from the committed PMC passes (tools/pmc_traffic.py)
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
-            if not os.path.exists(pmc):
-                pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+            pmc = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"))
+                        if os.path.exists(f)), "")
             if os.path.exists(pmc):
                 # PMC keys carry every template argument ("gemm_bf16_pp_kernel<true,true,3,0,false>"): pick the instantiations
                 # that make up this profile variant (a_rc, b_rc, tr_mode), launch-weighted
@@ -263,6 +333,9 @@ def main():
                     stem, targs = key.split("<")[0], key.split("<")[1].rstrip(">").split(",")
                     if mode == 8:            # ping-pong kernel, incl. the grouped weight-gradient launches
                         return stem in ("gemm_bf16_pp_kernel", "gemm_bf16_pp_group_kernel") and tuple(targs[:2]) == ab
+                    if mode in (12, 13):     # free-running schedule: <A_RC, B_RC, EPI, BVIEW, MT>
+                        return (stem == "gemm_bf16_fr_kernel" and tuple(targs[:2]) == ab
+                                and targs[-1] == ("192" if mode == 13 else "256"))
                     if mode == 11:           # eight-wave kernel: <B_RC, EPI>, A always K-contiguous
                         return stem == "gemm_bf16_dma8_kernel" and not a_rc and targs[0] == ab[1]
                     if stem != "gemm_bf16_dma_kernel" or tuple(targs[:2]) != ab:
@@ -290,10 +363,23 @@ def main():
             all_ms = sum(v["total_ms"] for v in summ.values())
             line["all_gemms"] = {"tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1), "ms_per_step": round(all_ms / args.steps, 3),
                                  "frac_of_mfma_peak": round(all_fl / (all_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+            enc = prof.by_tag("enc_layer")
+            if enc["launches"]:
+                # north_star's 0.40 is defined on exactly these: the speech encoder's transformer-layer Linears (QKV, out_proj,
+                # FFN1, FFN2), forward + data gradient + weight gradient, whatever kernel variant ran them
+                line["encoder_gemms"] = {"tflops": round(enc["tflops"], 1), "frac": round(enc["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                         "ms_per_step": round(enc["total_ms"] / args.steps, 3),
+                                         "launches_per_step": round(enc["launches"] / args.steps, 1),
+                                         "what": "speech-encoder transformer layers' Linear GEMMs: fwd + dgrad + wgrad (HIP events per launch)"}
             line["gemm_variants"] = {ops.GemmProfile.name(k): {"tflops": round(v["tflops"], 1),
                                                                   "ms_per_step": round(v["total_ms"] / args.steps, 3),
                                                                   "launches_per_step": v["launches"] // args.steps}
                                      for k, v in summ.items()}
+        if not args.no_profile:
+            try:
+                line["peaks_measured"] = measured_peaks(device)
+            except Exception as e:          # a reporting extra must never cost the bench line
+                line["peaks_measured"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -215,6 +215,12 @@ int smx_adafactor_step(const SmxAfParams* p, hipStream_t stream);
  * group owns the communicator); this entry is for hosts that create their own. */
 int smx_allreduce_bucket(void* comm, void* buf, size_t n, int dtype, hipStream_t stream);
 
+/* On-box peak probes for the measurement contract (the datasheet peaks the roofline fractions use AND
+ * what this box delivers): a pure v_mfma_f32_32x32x16_bf16 loop (returns the flops one launch issues; time it with events)
+ * and a 16-B-per-lane streaming copy (read + write). */
+double smx_probe_mfma(float* out, int blocks, int iters, hipStream_t stream);
+int smx_probe_copy(const void* src, void* dst, long long bytes, hipStream_t stream);
+
 /* ABI self-description */
 int smx_sizeof_SmxGemmParams(void);
 int smx_sizeof_SmxNormParams(void);

@@ -930,3 +930,51 @@ extern "C" int smx_dropout(const void* x, void* out, long long n, float p, unsig
     else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
+
+// ---------------------------------------------------------------- on-box peak probes (bench.py: `peaks_measured`)
+// What THIS box's matrix pipes and HBM deliver, next to the datasheet values the roofline fractions are quoted against
+// (SURVEY.md section 8d "state both").  MFMA: eight waves per CU (two per SIMD), four independent 32x32x16 bf16 accumulator
+// chains each on non-trivial operands (zero operands clock ~20 % higher, MI355X_MICROARCH.md DVFS note).  HBM: a 16-B-per-lane
+// streaming copy (read + write bytes counted).
+typedef __attribute__((ext_vector_type(16))) float probe_f32x16_t;
+__global__ __launch_bounds__(256) void probe_mfma_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8_t x, y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        x[e] = (short)(0x3f80 + ((lane * 37 + e * 11) & 0x7f) - ((lane + e) & 1) * 0x8000);       // +-[1, 2) bf16 patterns
+        y[e] = (short)(0x3f00 + ((lane * 13 + e * 29) & 0x7f) - ((lane * 3 + e) & 1) * 0x8000);
+    }
+    probe_f32x16_t a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += a0[e] + a1[e] + a2[e] + a3[e];
+    if (s == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;       // keeps the chains live, never true in practice
+}
+// -> flops issued by one launch (the caller times it with events): blocks x 4 waves x iters x 16 MFMAs x 2 * 32 * 32 * 16
+extern "C" double smx_probe_mfma(float* out, int blocks, int iters, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (blocks <= 0 || iters <= 0 || !out) return -1.0;
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, stream, out, iters);
+    if (hipGetLastError() != hipSuccess) return -1.0;
+    return (double)blocks * 4.0 * (double)iters * 16.0 * 2.0 * 32.0 * 32.0 * 16.0;
+}
+__global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n16) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int smx_probe_copy(const void* src, void* dst, long long bytes, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (bytes < 16 || !src || !dst) return SMX_EINVAL;
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 8), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, bytes / 16);
+    SMX_CHECK_LAUNCH();
+}

@@ -1004,8 +1004,10 @@ class Engine:
                 sv["layers"].append(None)
                 hidden.append(x)
                 continue
+            ops.GEMM_TAG = "enc_layer"
             x, lsv = self.layer_fwd(x, B, T, d, ec.num_attention_heads, ec.intermediate_size, self._w2v2_layer_names(i),
                                     stable, act, eps, drop=drop, klen=klen)
+            ops.GEMM_TAG = None
             sv["layers"].append(lsv)
             hidden.append(x)
         if stable:
@@ -1033,9 +1035,11 @@ class Engine:
             dx = self.ln_bwd(dx, sv["final_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
         for i in range(self.L - 1, -1, -1):
             if sv["layers"][i] is not None:
+                ops.GEMM_TAG = "enc_layer"
                 self._wg_begin()
                 dx = self.layer_bwd(dx, sv["layers"][i], self._w2v2_layer_names(i), stable, act)
                 self._wg_flush()
+                ops.GEMM_TAG = None
             if ws is not None:
                 ops.axpy_dev(dx, ws[0], ws[1], i, M * d, False, self.dt)
             self._stage(f"enc_layer{i}")

@@ -314,12 +314,12 @@ class GemmProfile:
     @staticmethod
     def name(key):
         a, b, mode = key
-        kern = "gemm_bf16_pp_kernel" if mode == 8 else "gemm_bf16_dma_kernel"
-        tile = ", 64x128 tiles" if mode == 9 else ", 256x128 tiles" if mode == 11 else ""
+        kern = "gemm_bf16_pp_kernel" if mode == 8 else "gemm_bf16_fr_kernel" if mode in (12, 13) else "gemm_bf16_dma_kernel"
+        tile = ", 64x128 tiles" if mode == 9 else ", 256x128 tiles" if mode == 11 else ", 192x256 tiles" if mode == 13 else ""
         return f"{kern}<{str(bool(a)).lower()},{str(bool(b)).lower()}> ({GemmProfile._ROLE[(a, b)]}{tile})"
 
     def __init__(self):
-        self.pool, self.used, self.recs = [], 0, []
+        self.pool, self.used, self.recs, self.tags = [], 0, [], []
 
     def events(self):
         if self.used + 2 > len(self.pool):
@@ -330,6 +330,20 @@ class GemmProfile:
 
     def add(self, key, e0, e1, flops, shape=None):
         self.recs.append((key, e0, e1, flops, shape))
+        self.tags.append(GEMM_TAG)
+
+    def by_tag(self, tag):
+        """Launches recorded while ops.GEMM_TAG == tag (the engine tags the speech encoder's transformer layers "enc_layer":
+        their Linear forward / data-gradient / weight-gradient GEMMs are what north_star's 0.40 is defined on):
+        -> dict(launches, total_ms, flops, tflops)."""
+        d = dict(launches=0, total_ms=0.0, flops=0.0)
+        for (key, e0, e1, fl, _), t in zip(self.recs, self.tags):
+            if t == tag:
+                d["launches"] += 1
+                d["total_ms"] += e0.elapsed_time(e1)
+                d["flops"] += fl
+        d["tflops"] = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["total_ms"] > 0 else 0.0
+        return d
 
     def by_shape(self):
         """-> {(variant, (M, N, K, nbatch, split_k)): dict(launches, total_ms, flops)} (tools/gpu_gemm_shapes.py)."""
@@ -356,6 +370,7 @@ class GemmProfile:
 
 
 GEMM_PROFILE = None
+GEMM_TAG = None          # set by the engine around stages whose GEMMs a report singles out (bench.py: encoder_gemms)
 
 
 class OpProfile:

@@ -24,7 +24,9 @@ for k, cs in agg.items():
     if m.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_conflict_frac"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"], 4)
     if m.get("GRBM_GUI_ACTIVE"):
-        d["mfma_busy_per_simd_of_gui_active"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"]), 4)
+        # MFMA utilisation against the PIPE's peak: busy cycles summed over the chip's 1024 SIMDs / (1024 x the kernel's
+        # duration in shader cycles); GRBM_GUI_ACTIVE = duration x shader clock as the hardware counted it
+        d["mfma_util_of_pipe_peak"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"]), 4)
     out[k] = d
 order = sorted(out, key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0) * out[k]["launches"])
 json.dump({"source": "rocprofv3 --kernel-trace --pmc <SQ counters> -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline "
