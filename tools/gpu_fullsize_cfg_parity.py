@@ -1,0 +1,169 @@
+"""Value parity at the FULL model dimensions of BASELINE configs 2, 4 and 5 against the CPU oracle, forward AND backward,
+on a few SHORT clips so that the oracle's fwd+bwd finishes in (tens of) seconds:
+
+    python tools/gpu_fullsize_cfg_parity.py CFG [B] [samples] [labels] [--bf16-oracle]
+
+  CFG 2  SpeechMixEED wav2vec2-base -> bart-base, down_scale 2
+  CFG 4  SpeechMixEED hubert-large-ll60k -> mbart-large-50 (d 1024, 24 stable-LN layers, "layer" CNN, FFN 4096, V 250 054), down_scale 8
+  CFG 5  SpeechMixSelf wav2vec2-large (12 of 24 layers) -> t5-large (frozen), down_scale 8, CE + KLD + MSE
+
+Random-init weights (seed 0, the bench's).  Compared: encoder hidden state, inputs_embeds, logits, loss and the gradient of
+EVERY trainable tensor (worst relative error reported with its name).  --bf16-oracle additionally runs the oracle with all
+weights and activations cast to torch.bfloat16 on the CPU - the reference arithmetic's own bf16 error against its fp32 self,
+the yardstick the HIP bf16 path is held to (tests/test_gpu_fullsize_parity.py: HIP-bf16 error <= 1.5 x oracle-bf16 error)."""
+import contextlib
+import io
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+CFGS = {"2": ("eed", "facebook/wav2vec2-base", "facebook/bart-base", 2, 0.0),
+        "4": ("eed", "hubert_large_ll60k", "facebook/mbart-large-50", 8, 0.0),
+        "5": ("self", "wav2vec2_large_960", "t5-large", 8, 0.5)}
+
+
+def build(cfg, dtype):
+    from speechmix_amd.model import SpeechMixEED, SpeechMixSelf
+    kind, enc, lm, ds, share = CFGS[cfg]
+    with contextlib.redirect_stdout(io.StringIO()):
+        if kind == "self":
+            return SpeechMixSelf(enc, lm, share_layer_ratio=share, down_scale=ds, compute_dtype=dtype, init_seed=0).eval()
+        return SpeechMixEED(enc, lm, share_layer_ratio=share, down_scale=ds, compute_dtype=dtype, init_seed=0).eval()
+
+
+def inputs(B, N, L, vocab, text):
+    g = torch.Generator().manual_seed(99)
+    wave = (torch.randn(B, N, generator=g) * 0.1).clamp_(-1, 1)
+    labels = torch.randint(4, vocab, (B, L), generator=g)
+    labels[:, -1] = 2
+    if B > 1:
+        labels[B - 1, -3:] = -100
+    tid = torch.randint(4, vocab, (B, L + 1), generator=g) if text else None
+    return wave, labels, tid
+
+
+def oracle_run(cfg, sd, ec, lc, wave, labels, text, n_layers, dt=torch.float32, trainable=None, threads=16):
+    """fwd + bwd of the oracle in dtype dt -> (leaves with .grad, outputs, seconds)."""
+    from oracle import speechmix_oracle as O
+    torch.set_num_threads(max(1, min(threads, len(os.sched_getaffinity(0)))))
+    kind, _, _, ds, _ = CFGS[cfg]
+    leaves = {}
+    for k, v in sd.items():
+        if k.endswith(("embed_tokens.weight", "lm_head.weight", "nlp_emb.weight")):      # aliases of the tied embedding (stored once)
+            continue
+        if v.is_floating_point():
+            t = v.to(dt).clone()
+            leaves[k] = t.requires_grad_(trainable is None or k in trainable)
+        else:
+            leaves[k] = v
+    t0 = time.perf_counter()
+    w = wave.to(dt)
+    if kind == "eed":
+        out = O.speechmix_eed_forward(leaves, ec, lc, w, labels=labels, down_scale=ds, num_speech_layers=n_layers)
+    else:
+        enc_sd, _, rest = O.split_state_dict(leaves)
+        last, _ = O.speech_encoder(enc_sd, ec, w, num_layers=n_layers)
+        x = O.length_adapters(rest, last, {2: 1, 4: 2, 8: 3}[ds])
+        emb = x @ rest["enc_to_dec_proj.weight"].t() + rest["enc_to_dec_proj.bias"]
+        dec_in = O.shift_tokens_right(labels, lc["pad_token_id"], lc["decoder_start_token_id"])
+        out = O.speechmix_self_losses(leaves, lc, emb, text, dec_in, labels)
+        out["encoder_last_hidden_state"], out["inputs_embeds"] = last, emb
+    out["loss"].float().backward()
+    return leaves, out, time.perf_counter() - t0
+
+
+def compare(model, hip_out, leaves, r, skip_grads=False):
+    def err(a, b):
+        return (a.detach().float().cpu() - b.detach().float()).abs().max().item()
+    res = {}
+    for k in ("encoder_last_hidden_state", "inputs_embeds", "raw_logits"):
+        res[k] = err(hip_out[k], r[k])
+        res[k + "_scale"] = r[k].detach().float().abs().max().item()
+    res["loss"] = abs(float(hip_out["loss"]) - float(r["loss"]))
+    res["loss_value"] = float(r["loss"])
+    top2 = r["raw_logits"].detach().float().topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 2 * res["raw_logits"]
+    res["argmax_checked"] = int(safe.sum())
+    res["argmax_equal"] = bool((hip_out["logits"].cpu()[safe] == r["raw_logits"].detach().float().argmax(-1)[safe]).all())
+    if not skip_grads:
+        named = dict(model.named_parameters())
+        worst, n = ("", 0.0), 0
+        for k, v in leaves.items():
+            if not (torch.is_tensor(v) and v.is_floating_point() and v.grad is not None) or k not in named:
+                continue
+            got = named[k].grad
+            if got is None:
+                continue
+            g = v.grad.float()
+            e = err(got, g) / max(g.abs().max().item(), 1e-12)
+            n += 1
+            if e > worst[1]:
+                worst = (k, e)
+        res["grads_checked"], res["grad_worst"], res["grad_worst_name"] = n, worst[1], worst[0]
+    return res
+
+
+def oracle_vs_oracle(leaves16, r16, leaves32, r32):
+    """The reference arithmetic's own bf16 error: same metrics as compare()."""
+    def err(a, b):
+        return (a.detach().float() - b.detach().float()).abs().max().item()
+    res = {k: err(r16[k], r32[k]) for k in ("encoder_last_hidden_state", "inputs_embeds", "raw_logits")}
+    res["loss"] = abs(float(r16["loss"]) - float(r32["loss"]))
+    worst = ("", 0.0)
+    for k, v in leaves32.items():
+        if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None and leaves16[k].grad is not None:
+            e = err(leaves16[k].grad, v.grad) / max(v.grad.abs().max().item(), 1e-12)
+            if e > worst[1]:
+                worst = (k, e)
+    res["grad_worst"], res["grad_worst_name"] = worst[1], worst[0]
+    return res
+
+
+def run(cfg, dtype, B=2, N=32000, L=8, ref=None, bf16_oracle=False):
+    """-> (errors of the HIP `dtype` path vs the fp32 oracle, oracle bundle for reuse [, oracle-bf16 errors])."""
+    kind = CFGS[cfg][0]
+    model = build(cfg, dtype)
+    ec, lc = model.encoder_model.config.to_dict(), model.decoder_model.config.to_dict()
+    wave, labels, text = inputs(B, N, L, lc["vocab_size"], kind == "self")
+    n_layers = model.num_speech_encoder_layers
+    trainable = {k for k, p in model.named_parameters() if p.requires_grad}
+    if ref is None:
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        leaves, r, secs = oracle_run(cfg, sd, ec, lc, wave, labels, text, n_layers, trainable=trainable)
+        ref = dict(leaves=leaves, r=r, secs=secs, sd=sd)
+        if bf16_oracle:
+            l16, r16, s16 = oracle_run(cfg, sd, ec, lc, wave, labels, text, n_layers, dt=torch.bfloat16, trainable=trainable)
+            ref["bf16"] = oracle_vs_oracle(l16, r16, leaves, r)
+            ref["bf16"]["seconds"] = s16
+            del l16, r16
+    kw = {"text_input_ids": text} if text is not None else {}
+    out = model(wave, labels=labels, return_model_detail=True, **kw)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    res = compare(model, out, ref["leaves"], ref["r"])
+    res["oracle_seconds"] = ref["secs"]
+    res["params_M"] = round(model.store.total / 1e6, 1)
+    del model
+    torch.cuda.empty_cache()
+    return res, ref
+
+
+if __name__ == "__main__":
+    cfg = sys.argv[1]
+    pos = [a for a in sys.argv[2:] if not a.startswith("--")]
+    B = int(pos[0]) if len(pos) > 0 else 2
+    N = int(pos[1]) if len(pos) > 1 else 32000
+    L = int(pos[2]) if len(pos) > 2 else 8
+    ref = None
+    for dtype in ("fp32", "bf16"):
+        res, ref = run(cfg, dtype, B, N, L, ref, bf16_oracle="--bf16-oracle" in sys.argv)
+        print(f"== config {cfg} {dtype}: B={B} N={N} L={L}, {res['params_M']} M parameters (oracle fwd+bwd {res['oracle_seconds']:.1f} s)")
+        for k, v in res.items():
+            print(f"   {k}: {v:.4e}" if isinstance(v, float) else f"   {k}: {v}")
+    if "bf16" in ref:
+        print("== oracle in bf16 vs oracle in fp32 (the reference arithmetic's own bf16 error):")
+        for k, v in ref["bf16"].items():
+            print(f"   {k}: {v:.4e}" if isinstance(v, float) else f"   {k}: {v}")
