@@ -80,7 +80,7 @@ def test_bf16_gemm_kernels_vs_fp32_reference_at_model_shapes(M, N, K):
     dY = torch.randn(M, N, generator=g).to(dev).bfloat16()
     ref_w = dY.float().t() @ A.float()                      # [N, K] weight gradient, reduction over M = 15 968 rows
     scw = ref_w.abs().max().item()
-    for mode in (1, 8, 11, 9):          # 128x128, 256x256 ping-pong, 256x128 eight-wave, 64x128
+    for mode in (1, 8, 11, 9, 12, 13):  # 128x128, 256x256 ping-pong, 256x128 eight-wave, 64x128, free-running 256x256 / 192x256
         Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
         ops.gemm(A, W, Y, M, N, K, ops.BF16, bias=bias, tr_mode=mode)
         e = (Y.float() - ref).abs().max().item()
@@ -92,7 +92,7 @@ def test_bf16_gemm_kernels_vs_fp32_reference_at_model_shapes(M, N, K):
         print(f"dgrad {M}x{N}x{K} mode {mode}: err {e:.3e} / {sc:.3e}")
         assert e <= 2 ** -7 * sc
         kst = (M + 63) // 64
-        for split in ((1, 7) if mode in (1, 8) else ()):            # (weight gradients: the first two kernels only)
+        for split in ((1, 7) if mode in (1, 8, 12) else ()):        # (weight gradients: 128x128, ping-pong, free-running)
             per = (kst + split - 1) // split
             sp = (kst + per - 1) // per
             S = torch.zeros(sp, N, K, dtype=torch.float32, device=dev)
@@ -115,7 +115,7 @@ def test_bf16_conv_view_gemm_vs_fp32_reference_at_512k_rows():
     x = (torch.randn(B * Tin, Cin, generator=g) * 0.5).to(dev).bfloat16()
     w = (torch.randn(Co, k * Cin, generator=g) * 0.03).to(dev).bfloat16()
     av = view(s * Cin, To, Tin * Cin)
-    for mode in (1, 8, 11):
+    for mode in (1, 8, 11, 12, 13):
         y = torch.zeros(B * To, Co, dtype=torch.bfloat16, device=dev)
         ops.gemm(x, w, y, B * To, Co, k * Cin, ops.BF16, av=av, tr_mode=mode)
         worst = 0.0

@@ -90,7 +90,11 @@ def compare(model, hip_out, leaves, r, skip_grads=False):
     res["argmax_equal"] = bool((hip_out["logits"].cpu()[safe] == r["raw_logits"].detach().float().argmax(-1)[safe]).all())
     if not skip_grads:
         named = dict(model.named_parameters())
-        worst, n = ("", 0.0), 0
+        worst, worst2, n = ("", 0.0), ("", 0.0), 0
+        # a tensor's error is taken relative to its own largest gradient entry, floored at 1e-3 of the largest gradient entry of
+        # the whole model: the key-projection biases have a mathematically ZERO gradient (softmax is invariant to them), what
+        # the oracle holds there is fp32 noise (1e-9) and a ratio against it means nothing
+        gmax = max(float(v.grad.abs().max()) for v in leaves.values() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None)
         for k, v in leaves.items():
             if not (torch.is_tensor(v) and v.is_floating_point() and v.grad is not None) or k not in named:
                 continue
@@ -98,11 +102,17 @@ def compare(model, hip_out, leaves, r, skip_grads=False):
             if got is None:
                 continue
             g = v.grad.float()
-            e = err(got, g) / max(g.abs().max().item(), 1e-12)
+            e = err(got, g) / max(g.abs().max().item(), 1e-3 * gmax)
+            # relative L2 error: insensitive to a single unit whose ReLU pre-activation sits within rounding of 0 (the
+            # derivative there is 0 on one side and 1 on the other: config 4's mBART FFNs, one unit in ~1.2 M on these inputs)
+            e2 = (got.detach().float().cpu() - g).norm().item() / max(g.norm().item(), 1e-3 * gmax * g.numel() ** 0.5)
             n += 1
             if e > worst[1]:
                 worst = (k, e)
+            if e2 > worst2[1]:
+                worst2 = (k, e2)
         res["grads_checked"], res["grad_worst"], res["grad_worst_name"] = n, worst[1], worst[0]
+        res["grad_worst_l2"], res["grad_worst_l2_name"] = worst2[1], worst2[0]
     return res
 
 
@@ -113,9 +123,10 @@ def oracle_vs_oracle(leaves16, r16, leaves32, r32):
     res = {k: err(r16[k], r32[k]) for k in ("encoder_last_hidden_state", "inputs_embeds", "raw_logits")}
     res["loss"] = abs(float(r16["loss"]) - float(r32["loss"]))
     worst = ("", 0.0)
+    gmax = max(float(v.grad.abs().max()) for v in leaves32.values() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None)
     for k, v in leaves32.items():
         if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None and leaves16[k].grad is not None:
-            e = err(leaves16[k].grad, v.grad) / max(v.grad.abs().max().item(), 1e-12)
+            e = err(leaves16[k].grad, v.grad) / max(v.grad.abs().max().item(), 1e-3 * gmax)
             if e > worst[1]:
                 worst = (k, e)
     res["grad_worst"], res["grad_worst_name"] = worst[1], worst[0]
