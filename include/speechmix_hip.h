@@ -128,6 +128,9 @@ typedef struct SmxCEParams {
     const float* logits; const long long* labels; float* loss; long long* argmax; void* dlogits; float* lse;
     int M, V; long long ldl, ldd; float gscale;
     const float* logits_t; float* kld; float kld_scale;   /* SpeechMixSelf KLD term, ref:speechmix/model.py:257-259 */
+    /* row-chunked calls (the LM head streamed over row chunks, ref:train.py:312-313 on logits memory): the mean's denominator is
+     * the count of valid labels in count_labels[0 .. count_M) - the whole batch - instead of this call's own rows */
+    const long long* count_labels; int count_M;
 } SmxCEParams;
 int smx_cross_entropy(const SmxCEParams* p, int dtype, hipStream_t stream);
 

@@ -105,7 +105,8 @@ class CEParams(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("labels", C.c_void_p), ("loss", C.c_void_p), ("argmax", C.c_void_p),
                 ("dlogits", C.c_void_p), ("lse", C.c_void_p), ("M", C.c_int), ("V", C.c_int),
                 ("ldl", C.c_longlong), ("ldd", C.c_longlong), ("gscale", C.c_float),
-                ("logits_t", C.c_void_p), ("kld", C.c_void_p), ("kld_scale", C.c_float)]
+                ("logits_t", C.c_void_p), ("kld", C.c_void_p), ("kld_scale", C.c_float),
+                ("count_labels", C.c_void_p), ("count_M", C.c_int)]
 
 
 class OptParams(C.Structure):

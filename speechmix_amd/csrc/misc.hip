@@ -360,6 +360,10 @@ struct SmxCEParams {
     const float* logits_t;     // teacher logits [M, ldl] or null
     float* kld;                // scalar, atomically accumulated (already divided by the batch size)
     float kld_scale;           // 1 / batch size
+    // Row-chunked use (the LM head streamed over row chunks so that [B L, V] logits are never materialised, Engine.lm_losses):
+    // the mean's denominator is the number of valid labels of the WHOLE batch - count over count_labels[0 .. count_M) when set
+    const long long* count_labels;
+    int count_M;
 };
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
@@ -370,7 +374,9 @@ __global__ __launch_bounds__(256) void ce_kernel(SmxCEParams p) {
     const float* z = p.logits + (long long)row * p.ldl;
     float nvalid = 0.f;
     if (p.labels) {
-        for (int i = tid; i < p.M; i += 256) nvalid += p.labels[i] != -100 ? 1.f : 0.f;
+        const long long* cl = p.count_labels ? p.count_labels : p.labels;
+        const int cm = p.count_labels ? p.count_M : p.M;
+        for (int i = tid; i < cm; i += 256) nvalid += cl[i] != -100 ? 1.f : 0.f;
         nvalid = block_sum(nvalid, sh);
     }
     float mx = -INFINITY;
@@ -469,7 +475,9 @@ __global__ __launch_bounds__(256) void ce_fast_kernel(SmxCEParams p) {
     const float4* z4 = reinterpret_cast<const float4*>(z);
     const int nv4 = p.V >> 2;
     float nvalid = 0.f;
-    for (int i = tid; i < p.M; i += 256) nvalid += p.labels[i] != -100 ? 1.f : 0.f;
+    const long long* cl = p.count_labels ? p.count_labels : p.labels;
+    const int cm = p.count_labels ? p.count_M : p.M;
+    for (int i = tid; i < cm; i += 256) nvalid += cl[i] != -100 ? 1.f : 0.f;
     nvalid = block_sum(nvalid, sh);
     CeRun a = {-INFINITY, 0.f, 0x7fffffff};
     for (int j4 = tid; j4 < nv4; j4 += 256) {

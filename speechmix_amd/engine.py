@@ -1170,7 +1170,30 @@ class Engine:
         ops.attn_bias_scatter(dbias, buckets.reshape(-1).to(torch.int32).contiguous(), self.G(tname), H, T, T,
                               self.lc.relative_attention_num_buckets)
 
-    def lm_fwd(self, inputs_embeds, input_ids, dec_ids, B, S, Ld, training, enc_klen=None):
+    def head_chunk_rows(self, Md, Vp):
+        """Rows per chunk of the streamed LM head, or 0 when the head runs as one GEMM.  The [B L, V] fp32 logits (+ their
+        gradient in the compute dtype) are what the reference's author trims with `preprocess_logits_for_metrics`
+        (ref:train.py:312-313): 0.3 GB at config 2, 1.5 GB at config 4 (V = 250 054).  Streaming computes them chunk by chunk
+        inside the loss (forward) and again inside backward: they are never materialised, at the price of one more head
+        GEMM per step and one read-modify-write pass over the tied embedding's fp32 gradient per chunk (config 4, B = 32:
+        80.3 -> 87.5 ms/step with 128-row chunks for 2 GB less peak memory of 38.6 GB - measured round 3 - so `auto` only streams
+        when logits + gradient exceed 2 GB, in chunks of up to 1 GB).  SMX_HEAD_STREAM = auto | 0 | 1 | <rows>."""
+        mode = os.environ.get("SMX_HEAD_STREAM", "auto")
+        es = 2 if self.dt == BF16 else 4
+        total = Md * Vp * (4 + es)
+        if mode == "0" or (mode == "auto" and total <= (2048 << 20)):
+            return 0
+        if mode.isdigit() and int(mode) > 1:
+            return min(Md, max(64, int(mode) // 64 * 64))
+        rows = (1024 << 20) // (Vp * (4 + es)) // 64 * 64
+        return min(Md, max(64, rows))
+
+    def _head_logits(self, sv, y_rows, out, rows):
+        """logits of `rows` decoder rows: tied-embedding head GEMM (+ final_logits_bias), fp32 out."""
+        ops.gemm(y_rows, self.W(sv["head"]), out, rows, sv["V"], self.lc.d_model, self.dt, cv=view(sv["Vp"]), bias=sv["flb"],
+                 out_f32=True, alpha=sv["head_alpha"])
+
+    def lm_fwd(self, inputs_embeds, input_ids, dec_ids, B, S, Ld, training, enc_klen=None, want_logits=True):
         """enc_klen: int32 [B] on the device = valid text-encoder positions per row (a right-padded `attention_mask`, the
         reference's hook ref:speechmix/model.py:132-136): masked as keys in the text encoder's self-attention and in the
         decoder's cross-attention (TF:models/bart/modeling_bart.py:741-760, 1010-1016)."""
@@ -1265,9 +1288,13 @@ class Engine:
         alpha = d ** -0.5 if (t5 and lc.tie_word_embeddings) else 1.0
         sv["head_alpha"] = alpha
         flb = self.st.module.get_buffer(lp + "final_logits_bias").view(-1) if not t5 else None
+        sv["flb"], sv["V"], sv["Vp"] = flb, V, Vp
+        if not want_logits and self.head_chunk_rows(B * Ld, Vp):
+            sv["logits"] = None                    # streamed head: lm_losses / lm_bwd compute them chunk by chunk
+            return None, enc, sv
         logits = self.new(B * Ld, Vp, dt=torch.float32)
-        ops.gemm(y, self.W(head), logits, B * Ld, V, d, self.dt, cv=view(Vp), bias=flb, out_f32=True, alpha=alpha)
-        sv["logits"], sv["V"], sv["Vp"] = logits, V, Vp
+        self._head_logits(sv, y, logits, B * Ld)
+        sv["logits"] = logits
         return logits, enc, sv
 
     # ------------------------------------------------------------------ greedy decoding with a KV cache (inference)
@@ -1477,10 +1504,25 @@ class Engine:
         Md, Ms = B * Ld, B * S
         emb_name, escale = sv["emb_name"], sv["escale"]
         lm_trainable = self.tr(head)
-        if lm_trainable:
-            self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a, side_ok=False)   # (tied embedding)
         dy = self.new(Md, d)
-        self.dgrad(dlogits, self.W(head), dy, Md, V, d, av=view(Vp), alpha=a)
+        if isinstance(dlogits, str):             # streamed head (lm_losses): recompute each chunk's logits, then its three products
+            R = self.head_chunk_rows(Md, Vp)
+            ws = self.workspace("head_logits", R * Vp, torch.float32)[:R * Vp].view(R, Vp)
+            dws = self.workspace("head_dlogits", R * Vp, self.tdt)[:R * Vp].view(R, Vp)
+            lab, y = sv["labels_flat"], sv["dec_out"]
+            scratch = self.zeros(1, dt=torch.float32)
+            am = self.new(R, dt=torch.int64)
+            for r0 in range(0, Md, R):
+                n = min(R, Md - r0)
+                self._head_logits(sv, y[r0:r0 + n], ws, n)
+                ops.cross_entropy(ws, lab[r0:r0 + n], scratch, am, dws, n, V, Vp, Vp, self.dt, count_labels=lab)
+                if lm_trainable:
+                    self.wgrad(dws, y[r0:r0 + n], self.G(head), n, V, d, dyv=view(Vp), alpha=a, side_ok=False)
+                self.dgrad(dws, self.W(head), dy[r0:r0 + n], n, V, d, av=view(Vp), alpha=a)
+        else:
+            if lm_trainable:
+                self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a, side_ok=False)   # (tied embedding)
+            self.dgrad(dlogits, self.W(head), dy, Md, V, d, av=view(Vp), alpha=a)
         if t5:
             dy = self.ln_bwd(dy, sv["dec_final_ln"], lp + "decoder.final_layer_norm.weight", None, Md, d, rms=True)
         elif lc.model_type == "mbart":
@@ -1558,14 +1600,34 @@ class Engine:
         return dh
 
     # ------------------------------------------------------------------ whole step
-    def lm_losses(self, e, dec_ids, labels, B, S, Ld, text_ids=None, training=False, want_grad=True, enc_klen=None):
+    def lm_losses(self, e, dec_ids, labels, B, S, Ld, text_ids=None, training=False, want_grad=True, enc_klen=None,
+                  want_logits=True):
         # `training` here is the LM's own mode (dropout): SpeechMixSelf keeps the LM in eval (ref:speechmix/model.py:239)
         """LM on `inputs_embeds` e [B*S,d] (+ optional SpeechMixSelf teacher pass on text_ids) -> losses and dlogits.
         Plain: CE (ref:speechmix/model.py:132-137).  Self: CE + KLD(batchmean) + MSE (ref:speechmix/model.py:235-266)."""
-        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training, enc_klen=enc_klen)
+        stream_ok = text_ids is None and not want_logits            # (SpeechMixSelf's KLD needs both logit sets at once)
+        logits, enc, lsv = self.lm_fwd(e, None, dec_ids.reshape(-1).contiguous(), B, S, Ld, training, enc_klen=enc_klen,
+                                       want_logits=not stream_ok)
         V, Vp = lsv["V"], lsv["Vp"]
         M = B * Ld
         argmax = self.new(M, dt=torch.int64)
+        if logits is None:
+            # streamed head: chunk -> logits -> CE / arg-max -> dropped; backward recomputes the chunk (lm_bwd)
+            R = self.head_chunk_rows(M, Vp)
+            ws = self.workspace("head_logits", R * Vp, torch.float32)[:R * Vp].view(R, Vp)
+            lab = labels.reshape(-1).contiguous() if labels is not None else None
+            ce = self.zeros(1, dt=torch.float32) if lab is not None else None
+            y = lsv["dec_out"]
+            for r0 in range(0, M, R):
+                n = min(R, M - r0)
+                self._head_logits(lsv, y[r0:r0 + n], ws, n)
+                ops.cross_entropy(ws, lab[r0:r0 + n] if lab is not None else None, ce, argmax[r0:r0 + n], None, n, V, Vp, Vp,
+                                  self.dt, count_labels=lab)
+            out = dict(logits=None, lm_enc_last=enc, argmax=argmax.view(B, Ld), lsv=lsv, loss=ce, dlogits=None, extra_denc=None)
+            if lab is not None:
+                out.update(ce=ce, dlogits="streamed" if want_grad else None)
+                lsv["labels_flat"] = lab
+            return out
         out = dict(logits=logits, lm_enc_last=enc, argmax=argmax.view(B, Ld), lsv=lsv, loss=None, dlogits=None, extra_denc=None)
         if labels is None:
             ops.cross_entropy(logits, None, None, argmax, None, M, V, Vp, Vp, self.dt)
@@ -1662,7 +1724,7 @@ class Engine:
         self._stage("frontend")
 
     def forward(self, wave, dec_ids, labels, training=False, prompt_ids=None, text_ids=None, weighted_sum=False,
-                lm_training=None, sample_lengths=None, lm_mask=True):
+                lm_training=None, sample_lengths=None, lm_mask=True, want_logits=True):
         """wave [B,N] fp32 cuda; dec_ids [B,Ld] int64; labels [B,Ld] int64 or None; text_ids [B,Lt] (SpeechMixSelf);
         prompt_ids [P] int64: token ids of a text prompt whose embeddings are prepended to every clip
         (ref:speechmix/model.py:168-171, batch-expanded like ref:speechmix/hf_model.py:433-436)."""
@@ -1677,7 +1739,7 @@ class Engine:
         if ex.get("lm_lengths") is not None and lm_mask:
             enc_klen = torch.tensor(ex["lm_lengths"], dtype=torch.int32, device=self.dev)
         lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
-                            training=training if lm_training is None else lm_training, enc_klen=enc_klen)
+                            training=training if lm_training is None else lm_training, enc_klen=enc_klen, want_logits=want_logits)
         self.mark("fwd:lm")
         self.saved = dict(state, lm=lo["lsv"], dlogits=lo["dlogits"], extra_denc=lo["extra_denc"], Ld=Ld)
         return dict(loss=lo["loss"], argmax=lo["argmax"], logits=lo["logits"], enc_last=ex["enc_last"],

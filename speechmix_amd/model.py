@@ -101,8 +101,11 @@ class _StepFn(torch.autograd.Function):
         text_ids, prompt_ids = model._pending_text_ids, model._pending_prompt_ids
         lengths = getattr(model, "_pending_lengths", None)
         model._pending_text_ids = model._pending_prompt_ids = model._pending_lengths = None
+        want_logits = getattr(model, "_pending_want_logits", True)
+        model._pending_want_logits = True
         out = model.engine.forward(wave, dec_ids, labels, training=training, text_ids=text_ids, prompt_ids=prompt_ids,
-                                   weighted_sum=model.weighted_sum, lm_training=model._lm_training(), sample_lengths=lengths)
+                                   weighted_sum=model.weighted_sum, lm_training=model._lm_training(), sample_lengths=lengths,
+                                   want_logits=want_logits)
         ctx.model = model
         ctx.n_params = len(params)
         model._last = out
@@ -631,11 +634,13 @@ class SpeechMixEED(nn.Module):
         if want_grad:
             params = tuple(self.store.params.values()) if self.autograd_param_inputs else ()
             self._pending_text_ids, self._pending_prompt_ids, self._pending_lengths = text, prompt_ids, sample_lengths
+            self._pending_want_logits = bool(return_model_detail)
             loss = _StepFn.apply(self, wave, dec, lab, training, self._anchor, *params)
             out = self._last
         else:
             out = self.engine.forward(wave, dec, lab, training=training, text_ids=text, prompt_ids=prompt_ids,
-                                      weighted_sum=self.weighted_sum, lm_training=self._lm_training(), sample_lengths=sample_lengths)
+                                      weighted_sum=self.weighted_sum, lm_training=self._lm_training(), sample_lengths=sample_lengths,
+                                      want_logits=bool(return_model_detail))
             loss = out["loss"].view(()) if out["loss"] is not None else None
             self.engine.saved = None
         if return_model_detail:

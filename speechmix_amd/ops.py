@@ -668,9 +668,10 @@ def dropout_colsum(x, out, M, N, p, seed, colsum_out, dtype, alpha=1.0, folds=No
 
 
 def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, gscale=1.0, lse=None, logits_t=None,
-                  kld=None, kld_scale=0.0):
+                  kld=None, kld_scale=0.0, count_labels=None):
+    """count_labels: all labels of the batch when this call covers a row chunk of it (the mean's denominator stays global)."""
     p = L.CEParams(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(argmax), _ptr(dlogits), _ptr(lse), M, V, ldl, ldd, gscale,
-                   _ptr(logits_t), _ptr(kld), kld_scale)
+                   _ptr(logits_t), _ptr(kld), kld_scale, _ptr(count_labels), count_labels.numel() if count_labels is not None else 0)
     nb = M * V * (8 + (_es(dtype) if dlogits is not None else 0))          # two passes over the fp32 logits + the gradient written
     with _Span("cross_entropy", nb):
         L.check(L.lib().smx_cross_entropy(C.byref(p), dtype, _stream()), "smx_cross_entropy")

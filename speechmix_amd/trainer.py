@@ -131,7 +131,7 @@ class StepRunner:
         text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
         out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(),
                           training=m.training and m.encoder_model.training, text_ids=text, weighted_sum=m.weighted_sum,
-                          lm_training=m._lm_training())
+                          lm_training=m._lm_training(), want_logits=False)
         # micro-batches before the last only add their gradient (no stage reports: nothing is reduced or updated yet)
         cb, eng.stage_cb = eng.stage_cb, (eng.stage_cb if last else None)
         try:

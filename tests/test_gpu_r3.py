@@ -227,3 +227,29 @@ def test_standalone_lm_loop_zeroes_the_flat_gradient_between_iterations():
     out.loss.backward()
     acc = dict(model.named_parameters())[key].grad.detach().float().cpu()
     assert _err(acc, 2 * gold["grad::" + key]) <= 6e-3 * gold["grad::" + key].abs().max().item()
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_streamed_lm_head_equals_the_materialised_one(dtype, tol, monkeypatch):
+    """SMX_HEAD_STREAM: the LM head + CE streamed over row chunks (logits never materialised; recomputed per chunk in backward)
+    gives the loss, arg-max ids and EVERY gradient of the one-GEMM form (same kernels, same per-row arithmetic; the tied
+    embedding's gradient is summed chunk by chunk, hence not bit-identical)."""
+    res = {}
+    for mode in ("0", "64"):                     # 64-row chunks: 2 x 9 = 18 rows -> one ragged chunk; use a longer label row
+        monkeypatch.setenv("SMX_HEAD_STREAM", mode)
+        model, inp, gold, m = _build("eed_w2v2_bart", dtype)
+        labels = torch.randint(3, 128, (2, 70), generator=torch.Generator().manual_seed(5))
+        labels[1, -9:] = -100
+        out = model(inp["input_values"], labels=labels)            # no return_model_detail -> the streamed path when enabled
+        out["loss"].backward()
+        eng = model.engine
+        assert (eng.head_chunk_rows(140, 128) > 0) == (mode != "0")
+        res[mode] = (out["loss"].item(), out["logits"].cpu().clone(), {k: p.grad.detach().float().cpu().clone()
+                                                                       for k, p in model.named_parameters() if p.grad is not None})
+    l0, a0, g0 = res["0"]
+    l1, a1, g1 = res["64"]
+    assert abs(l0 - l1) <= tol * max(1.0, abs(l0)) and torch.equal(a0, a1)
+    assert g0.keys() == g1.keys()
+    worst = max(((g0[k] - g1[k]).abs().max().item() / max(g0[k].abs().max().item(), 1e-8), k) for k in g0)
+    print(f"[streamed head {dtype}] loss {l0:.6f} vs {l1:.6f}; worst gradient difference {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] <= (1e-4 if dtype == "fp32" else 5e-2)

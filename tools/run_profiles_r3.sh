@@ -11,16 +11,16 @@ export TMPDIR=/tmp SMX_TUNE_FILE=$PWD/$O/tune.json
 timeout 600 python3 bench.py > $O/bench.json 2> $O/bench.err
 tail -c 400 $O/bench.json
 # 2. kernel trace + stats of the same command (timed steps + event-instrumented steps)
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 bench.py --no-cpu-baseline > $O/trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 bench.py --no-cpu-baseline > $O/trace.log 2>&1
 T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
 S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$T" ] && python3 tools/rocprof_steps.py "$T" 3 > $O/kernel_steps.txt 2>&1
 [ -n "$S" ] && cp "$S" $O/kernel_stats.csv
 # 3. PMC passes (short run: 2 warm-up + 2 steps)
 ARGS="bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-profile --no-eval-leg"
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 $ARGS > $O/pmc_fetch.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $ARGS > $O/pmc_write.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/pmc_sq -o p -- python3 $ARGS > $O/pmc_sq.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 $ARGS > $O/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $ARGS > $O/pmc_write.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/pmc_sq -o p -- python3 $ARGS > $O/pmc_sq.log 2>&1
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 Q=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1)
