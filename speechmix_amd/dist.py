@@ -11,10 +11,53 @@ One process per GPU; no collective on the forward path (pure data parallel: each
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+# How a bucket is summed across ranks (SMX_ALLREDUCE):
+#   sum    one fp32 all-reduce per bucket (default)
+#   rs_ag  reduce-scatter + all-gather on the bucket's world-divisible part (two half-volume collectives: on point-to-point xGMI
+#          links the ring all-reduce is per-link bound, and the two halves can be scheduled apart); remainder all-reduced
+#   bf16   the bucket is cast to bf16, all-reduced, cast back: half the bytes over xGMI, bf16 rounding of the summed gradient
+#          (the sum itself runs in bf16: a precision trade the reference's fp32 DDP buckets do not make - opt-in only)
+# Every rank must use the same mode.  UNMEASURED on hardware by this builder (single-GPU boxes): switches for the scaling runs.
+ALLREDUCE_MODE = os.environ.get("SMX_ALLREDUCE", "sum")
+
+
+def reduce_bucket(t: torch.Tensor, group=None, mode: Optional[str] = None):
+    """Sum `t` (a contiguous fp32 slice of the flat gradient) over the group, in place."""
+    mode = mode or ALLREDUCE_MODE
+    world = dist.get_world_size(group)
+    if mode == "bf16":
+        c = t.to(torch.bfloat16)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(c)
+        return
+    if mode == "rs_ag" and world > 1 and dist.get_backend(group) == "nccl":
+        n = t.numel() - t.numel() % world
+        if n:
+            sh = n // world
+            r = dist.get_rank(group)
+            mine = t[r * sh:(r + 1) * sh]
+            dist.reduce_scatter_tensor(mine, t[:n], op=dist.ReduceOp.SUM, group=group)
+            dist.all_gather_into_tensor(t[:n], mine, group=group)
+        if n < t.numel():
+            dist.all_reduce(t[n:], op=dist.ReduceOp.SUM, group=group)
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def share_tuner_picks(group=None, src: int = 0):
+    """Every rank adopts rank `src`'s kernel picks (speechmix_amd.ops tuner state): ranks that tuned independently can
+    launch different kernel variants for the same shape - different K splits, hence different bf16 roundings and different
+    per-rank step times.  Picks a rank made that `src` has not are kept."""
+    from . import ops
+    box = [ops.tuner_state() if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    ops.load_tuner_state(box[0])
 
 
 def stage_ranges(offsets: Dict[str, Tuple[int, int, tuple]], num_speech_layers: int, max_bucket_elems: int = 64 << 20,
@@ -84,10 +127,10 @@ class GradReducer:
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 for a, b in self.stages[name]:
-                    dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+                    reduce_bucket(self.g[a:b], self.group)
         else:
             for a, b in self.stages[name]:
-                dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, group=self.group)
+                reduce_bucket(self.g[a:b], self.group)
 
     def finish(self):
         """Reduce whatever has not been reported yet and make the compute stream wait for the side stream."""

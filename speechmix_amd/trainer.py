@@ -122,6 +122,10 @@ class StepRunner:
         labels = labels.to(st.device)
         if decoder_input_ids is None:
             decoder_input_ids = shift_tokens_right(labels, lc.pad_token_id, lc.decoder_start_token_id)
+        if self.world > 1 and self._micro == 0 and self.t in (1, 3):
+            # after the first steps have tuned: all ranks adopt rank 0's kernel picks (same kernels, same bf16 roundings, same pace)
+            from .dist import share_tuner_picks
+            share_tuner_picks()
         ga, first = self.grad_accum, self._micro == 0
         last = self._micro == ga - 1
         self._micro = 0 if last else self._micro + 1

@@ -139,3 +139,48 @@ def test_reducer_on_real_config2_layout_with_layerdrop_and_grad_accum():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res[0][1] and res[1][1] and res[0][2] and res[0][3] == res[1][3], res
+
+
+def _worker_modes(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from speechmix_amd import ops
+        from speechmix_amd.dist import reduce_bucket, share_tuner_picks
+        torch.manual_seed(7 + rank)
+        g = torch.randn(1003)
+        ref = g.clone()
+        dist.all_reduce(ref)
+        out = {}
+        for mode in ("sum", "rs_ag", "bf16"):          # rs_ag falls back to the all-reduce on gloo (no reduce-scatter there)
+            t = g.clone()
+            reduce_bucket(t, mode=mode)
+            out[mode] = (t - ref).abs().max().item()
+        # tuner picks: rank 1 adopts rank 0's choice for a shared key and keeps its own extra key
+        ops._TUNED.clear()
+        ops._tuned_set(("shape", 1), 8 if rank == 0 else 12)
+        if rank == 1:
+            ops._tuned_set(("only_rank1",), 13)
+        share_tuner_picks()
+        picks = (ops._tuned_get(("shape", 1)), ops._tuned_get(("only_rank1",)))
+        q.put((rank, out, picks))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_modes_and_shared_tuner_picks_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_modes, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, picks in res:
+        assert out["sum"] == 0.0 and out["rs_ag"] == 0.0
+        assert 0.0 < out["bf16"] < 5e-2                       # bf16 rounding of the summed gradient, nothing worse
+    assert res[0][2] == (8, None) and res[1][2] == (8, 13)
