@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout / LayerDrop / SpecAugment off")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the extra p=0 pass reported beside the train-mode number")
+    ap.add_argument("--seed", type=int, default=None, help="seed the host streams (np.random: SpecAugment, torch: LayerDrop) for A/B runs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -232,6 +233,10 @@ def main():
     # Training mode like HF Trainer's model.train(): dropout (hidden/attention/activation p=0.1 in the encoder, p=0.1
     # in BART), LayerDrop and SpecAugment are ON with the HF config defaults; --eval-mode switches them off.
     model.train(not args.eval_mode)
+    if args.seed is not None:
+        import numpy as np
+        np.random.seed(args.seed + rank)
+        torch.manual_seed(args.seed + rank)
     # optimizer: the reference trains with HF Trainer's optim="adafactor", lr 5e-4 (ref:train.py:298, 305); AdamW kept as a switch
     runner = StepRunner(model, lr=5e-4 if args.optimizer == "adafactor" else 4e-5, optimizer=args.optimizer, max_grad_norm=1.0)
     B = args.batch

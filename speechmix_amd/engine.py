@@ -367,13 +367,41 @@ class Engine:
     # gradients has 9-36 output tiles of 256 x 256 and needs 7 K slices to fill the chip: 7 fp32 slabs written and read back
     # per weight.  Together they have 108 tiles, so ONE launch over the concatenated work lists fills the chip with 2 slices:
     # 3.5x less slab traffic, one launch (and one tail) instead of four, and K loops of 125 tiles instead of 36 per item.
+    def _wg_side_stream(self):
+        # measured round 3 (same box, seeded, 20 steps): 32.74 / 32.82 vs 33.10 / 33.08 ms in one pair of runs, 32.85 / 32.77 vs
+        # 32.77 / 32.65 in the next - no reliable gain, so it stays an opt-in switch (gradients identical: tools/gpu_side_check.py)
+        if os.environ.get("SMX_WGRAD_SIDE", "0") != "1" or self.st.device.type != "cuda" or self.dt != BF16:
+            return None
+        if getattr(self, "_wg_side", None) is None:
+            self._wg_side = torch.cuda.Stream()
+        return self._wg_side
+
+    def _join_wg(self, stage):
+        """The grouped weight gradients of `stage` are complete: join their stream, then report the stage."""
+        torch.cuda.current_stream().wait_stream(self._wg_side)
+        self._stage(stage)
+
     def _wg_begin(self):
         self._wg_group = [] if (_WGRAD_GROUP and self.dt == BF16) else None
 
-    def _wg_flush(self):
+    def _wg_flush(self, side=None):
+        """side: a HIP stream - the grouped launch (and its slab reduction) go there, behind everything the current stream has
+        enqueued so far; the caller joins it before it reports the stage (speech_bwd: one layer later, so that the launch -
+        216 work items on 256 CUs - runs beside the next layer's data-gradient chain, which takes the 40 CUs it leaves idle)."""
         grp, self._wg_group = getattr(self, "_wg_group", None), None
         if not grp:
-            return
+            return False
+        if side is not None and len(grp) > 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            self._wg_group = grp
+            with torch.cuda.stream(side):
+                self._wg_flush()
+            for dy, x, *_ in grp:                 # the allocator must not hand their memory out while the side stream reads it
+                dy.record_stream(side)
+                x.record_stream(side)
+            return True
         if len(grp) == 1:
             dy, x, gw, N, K, M, av, bv, alpha = grp[0]
             self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True)
@@ -1033,16 +1061,32 @@ class Engine:
             ops.axpy_dev(dx, dxw, sw, self.L, M * d, True, self.dt)
         if stable:
             dx = self.ln_bwd(dx, sv["final_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
+        pending = None          # stage whose grouped weight gradients are still running on the second stream
         for i in range(self.L - 1, -1, -1):
             if sv["layers"][i] is not None:
                 ops.GEMM_TAG = "enc_layer"
                 self._wg_begin()
                 dx = self.layer_bwd(dx, sv["layers"][i], self._w2v2_layer_names(i), stable, act)
-                self._wg_flush()
+                # The layer's grouped weight-gradient launch can go to a second stream, joined one layer LATER
+                # (SMX_WGRAD_SIDE=1; default: on this stream, joined at once): nothing downstream needs it before its stage is reported
+                if pending is not None:
+                    self._join_wg(pending)
+                    pending = None
+                on_side = self._wg_flush(side=self._wg_side_stream())
                 ops.GEMM_TAG = None
+                if on_side:
+                    if ws is not None:
+                        ops.axpy_dev(dx, ws[0], ws[1], i, M * d, False, self.dt)
+                    pending = f"enc_layer{i}"
+                    continue
+            if pending is not None:              # (a dropped layer: stages are still reported in layer order on every rank)
+                self._join_wg(pending)
+                pending = None
             if ws is not None:
                 ops.axpy_dev(dx, ws[0], ws[1], i, M * d, False, self.dt)
             self._stage(f"enc_layer{i}")
+        if pending is not None:
+            self._join_wg(pending)
         if not stable:
             dx = self.ln_bwd(dx, sv["enc_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
         else:
