@@ -201,10 +201,10 @@ __device__ __forceinline__ void fr_kernel_body() {
             ++seq;
         }
         if (fast_epi) {
-            pp_epilogue_fast<EPI, GRP, NB>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
+            pp_epilogue_fast<EPI, GRP, NB, B_RC>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
                                        it.ze, lane, gc);
         } else {
-            pp_epilogue<GRP, NB>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
+            pp_epilogue<GRP, NB, B_RC>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -131,9 +131,18 @@ __device__ __forceinline__ void pp_decode(const SmxGemmParams& p, const PPDiv& d
     it.nk = max(min(d.kst, it.ks0 + d.per) - it.ks0, 0);
 }
 
-// LDS images.  A units and all RC units use the 128x128 kernels' images (kc_addr / rc_addr).  KC B units swizzle
-// their 16-B chunks with pp_bswz so that the permuted fragment rows {8 (i>>2) + 4 j + (i & 3)} stay conflict-free.
+// LDS images.  A units use the 128x128 kernels' images (kc_addr / rc_addr).  KC B units swizzle their 16-B chunks with pp_bswz
+// so that the permuted fragment rows {8 (i>>2) + 4 j + (i & 3)} stay conflict-free.
 __device__ __forceinline__ int pp_bswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+// RC B units (round 3): k-row k is 256 B = 16 chunks of 8 columns, chunk c stored at slot c ^ pp_rcb_swz(k).  The permuted
+// fragment read takes 8 B (4 columns) of each of 4 consecutive chunks per k-row - HALF of every chunk it touches - so with the
+// rc_addr image (what rounds 1-2 used here) the 16 k-rows of one ds_read_b64_tr_b16 met on 32 of the 64 banks: a 4-way
+// conflict where 512 B need 2 cycles (PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25 on every kernel with a
+// rows-contiguous B, 0.00 without).  Here (a) the four k-rows of a quad go to four different 64-B blocks (slot bits 2-3 <- k & 3),
+// (b) k-rows 8 apart in the same block swap chunk parity (slot bit 0 <- bit 3 of k) and (c) odd lane quads read the OTHER half
+// of their chunk (fragment j of lane quad c holds columns 8 c + 4 (j ^ (c & 1)) ..: still 8 consecutive columns per lane
+// after both fragments; the epilogues swap the two halves back, template flag BSW), so one read covers all 64 banks twice.
+__device__ __forceinline__ int pp_rcb_swz(int k) { return ((k & 3) << 2) | ((k >> 3) & 1); }
 
 // MT: rows of the output tile (256, or 192 = two wave-row groups of 96: unit AH1 then holds 2 x 32 rows)
 template <bool RC, bool IS_A, bool VIEW, int MT = PP_BM>
@@ -174,7 +183,7 @@ struct PPOperand {
         } else {
             const int kl = wave * 4 + (lane >> 4), g16 = lane & 15;      // rc_swz(kl) is the same for both passes
             kc = 0;                                                      // (RC recomputes its k-row from the lane id)
-            const int hc = ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8;
+            const int hc = IS_A ? ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8 : (g16 ^ pp_rcb_swz(kl)) * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int gc = grow(h, hc);
@@ -295,7 +304,7 @@ struct PPIssue {
 };
 
 // B fragment j (0/1) of a 32-column half for the wave-column block starting at unit row r32: fragment column i of lane
-// i <-> logical column 8 (i >> 2) + 4 j + (i & 3)
+// i <-> logical column 8 (i >> 2) + 4 j + (i & 3)   (RC: 4 (j ^ ((i >> 2) & 1)), see pp_rcb_swz)
 template <bool RC>
 __device__ __forceinline__ bf16x8_t pp_bfrag(const char* unit, int r32, int j, int kk, int lane) {
     const int i = lane & 15, g = lane >> 4;
@@ -304,20 +313,23 @@ __device__ __forceinline__ bf16x8_t pp_bfrag(const char* unit, int r32, int j, i
         const int row = r32 + 8 * (i >> 2) + 4 * j + (i & 3);
         f.u = *reinterpret_cast<const uint4*>(unit + row * 128 + (((kk * 4 + g) ^ pp_bswz(row)) << 4));
     } else {
-        const int q = i >> 2, col = r32 + 8 * (i & 3) + 4 * j;
-        const int kb = kk * 32 + 8 * g + q;
-        f.h[0] = lds_tr_b64(unit + rc_addr(kb, col));
-        f.h[1] = lds_tr_b64(unit + rc_addr(kb + 4, col));
+        const int q = i >> 2, c = i & 3;
+        const int kb = kk * 32 + 8 * g + q;                          // pp_rcb_swz(kb) == pp_rcb_swz(kb + 4) == (q << 2) | (g & 1)
+        const int a = kb * 256 + ((((r32 >> 3) + c) ^ ((q << 2) | (g & 1))) << 4) + ((j ^ (c & 1)) << 3);
+        f.h[0] = lds_tr_b64(unit + a);
+        f.h[1] = lds_tr_b64(unit + a + 4 * 256);
     }
     return f.v;
 }
 
 // acc[rh*4+a][2 ch + j][r]: row mw0 + rh*64 + a*16 + (lane & 15), column nw0 + ch*32 + 8 (lane >> 4) + 4 j + r
-template <bool GRP = false, int NB = 8>
+// BSW (rows-contiguous B): lanes of odd 16-lane groups hold the two 4-column halves in the other order (pp_rcb_swz)
+template <bool GRP = false, int NB = 8, bool BSW = false>
 __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[NB][4], int mw0, int nw0, long long zc, long long zbias,
                                             long long ze, int lane, int gi = 0) {
     const SmxGemmParams& p = pp_kernarg_g<GRP>(gi);
     const int i16 = lane & 15, g = lane >> 4;
+    const bool sw = BSW && (g & 1);
     float bs[2][8];
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
@@ -352,6 +364,14 @@ __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[NB][4], int mw0, int 
             case 12: { PP_GET(6, 0) } break; case 13: { PP_GET(6, 1) } break; case 14: { PP_GET(7, 0) } break; default: { PP_GET(7, 1) } break;
         }
 #undef PP_GET
+        if (BSW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = x[e], hi = x[e + 4];
+                x[e] = sw ? hi : lo;
+                x[e + 4] = sw ? lo : hi;
+            }
+        }
         const int a8 = it >> 1, ch = it & 1;
         const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
         const int n = nw0 + ch * 32 + g * 8;
@@ -374,11 +394,12 @@ __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
     return !(m & 7) && !(p.N & 7);
 }
 
-template <int EPI, bool GRP = false, int NB = 8>
+template <int EPI, bool GRP = false, int NB = 8, bool BSW = false>
 __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0, int nw0, int n0, const char* bias_lds,
                                                  long long zc, long long ze, int lane, int gi = 0) {
     const SmxGemmParams& p = pp_kernarg_g<GRP>(gi);
     const int i16 = lane & 15, g = lane >> 4;
+    const bool sw = BSW && (g & 1);
     const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
     // bias: the item's 256-column slice was put into LDS by an LDS-DMA issued when the item started (zeros beyond N)
     float bs[2][8];
@@ -458,6 +479,14 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                 const int n = nl + ch * 32;
                 float x[8] = {acc[a8][2 * ch][0], acc[a8][2 * ch][1], acc[a8][2 * ch][2], acc[a8][2 * ch][3],
                               acc[a8][2 * ch + 1][0], acc[a8][2 * ch + 1][1], acc[a8][2 * ch + 1][2], acc[a8][2 * ch + 1][3]};
+                if (BSW) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = x[e], hi = x[e + 4];
+                        x[e] = sw ? hi : lo;
+                        x[e + 4] = sw ? lo : hi;
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[ch][e]);
                 if (EPI == PP_EPI_F32) {

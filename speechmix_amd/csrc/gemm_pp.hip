@@ -183,10 +183,10 @@ __device__ __forceinline__ void pp_kernel_body(const KARG& karg) {
             for (int a = 0; a < 8; ++a) for (int j = 0; j < 4; ++j) sink += acc[a][j][0] + acc[a][j][1] + acc[a][j][2] + acc[a][j][3];
             if (sink == 1234.5f) reinterpret_cast<float*>(pp_kernarg_g<GRP>(0).C)[tid] = sink;
         } else if (fast_epi) {
-            pp_epilogue_fast<EPI, GRP>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
+            pp_epilogue_fast<EPI, GRP, 8, B_RC>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
                                        it.ze, lane, gc);
         } else {
-            pp_epilogue<GRP>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
+            pp_epilogue<GRP, 8, B_RC>(acc, it.m0 + wr * 128, it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
         }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();

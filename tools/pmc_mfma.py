@@ -25,8 +25,11 @@ for k, cs in agg.items():
         d["lds_conflict_frac"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"], 4)
     if m.get("GRBM_GUI_ACTIVE"):
         # MFMA utilisation against the PIPE's peak: busy cycles summed over the chip's 1024 SIMDs / (1024 x the kernel's
-        # duration in shader cycles); GRBM_GUI_ACTIVE = duration x shader clock as the hardware counted it
-        d["mfma_util_of_pipe_peak"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"]), 4)
+        # duration in shader cycles).  rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (checked against the kernel
+        # trace: 4.93 M counts for a 270.8-us launch = 8 x 2.27 GHz), so duration x clock = GRBM_GUI_ACTIVE / 8 and the
+        # denominator is 128 x GRBM_GUI_ACTIVE.  (Cross-check: the grouped weight gradient's 13.8 M MFMAs x 16 cycles =
+        # 221 M busy cycles, exactly the counter; 0.35 here = the 0.34 - 0.35 of 2.5 PF that bench.py times with HIP events.)
+        d["mfma_util_of_pipe_peak"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (128.0 * m["GRBM_GUI_ACTIVE"]), 4)
     out[k] = d
 order = sorted(out, key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0) * out[k]["launches"])
 json.dump({"source": "rocprofv3 --kernel-trace --pmc <SQ counters> -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline "
