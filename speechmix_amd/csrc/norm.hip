@@ -10,6 +10,7 @@
 #include "smx_common.h"
 
 #define LN_NCH 2  // 8-element chunks per lane -> D <= 64 * 8 * 2
+#define LN_BLOCKS_PER_CU 3   // resident blocks per CU of the fused backward (its launch bound)
 
 struct SmxNormParams {
     const void* x;        // [M, D] input (dtype T)
@@ -277,10 +278,9 @@ __global__ __launch_bounds__(256) void norm_bwd_param_kernel(SmxNormBwdParams p)
 // block would leave the chip short of blocks (M = 7 968: 498 blocks on 256 CUs ran at 1.3 TB/s, M = 1 024: 64 blocks) and to
 // halve the registers a wave holds (more waves per SIMD to overlap the row reductions with the loads).
 template <typename T, bool ACT, int PR>
-__global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p) {
+__global__ __launch_bounds__(256, PR == 1 ? LN_BLOCKS_PER_CU : 1) void norm_bwd_fused_kernel(SmxNormBwdParams p) {
     __shared__ float red[4][64][8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + w) * PR;
     const float invD = 1.0f / (float)p.D;
     float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
     float dc[ACT ? 1 : LN_NCH][8];                 // column sums of the masked dx (third partial row)
@@ -301,6 +301,12 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
             if (ACT && p.beta) load8(p.beta + c, bt[j]);
         }
     }
+    // persistent over row groups when launched with fewer blocks than groups (ln_grid): the column accumulators live across
+    // the groups and the block leaves ONE partial-row set - the LDS reduction below (six barrier pairs) was ~30 % of a
+    // block's time when it followed every 8 rows
+    const int ngroups = (p.M + 4 * PR - 1) / (4 * PR);
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int row0 = (grp * 4 + w) * PR;
     float xv[PR][LN_NCH][8], dv[PR][LN_NCH][8], mean[PR], rstd[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
             }
         }
     }
+    }   // row groups
 #pragma unroll
     for (int j = 0; j < LN_NCH; ++j) {
         if (64 * 8 * j >= p.D) break;
@@ -395,154 +402,6 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(SmxNormBwdParams p)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sum8[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
                 store8(p.partials + ((long long)blockIdx.x * npass + pass) * p.D + c, sum8);
-            }
-        }
-    }
-}
-
-// Variant of the fused kernel for narrow rows (D <= 512: the CNN's layer norms over 512 channels, where a lane holds one
-// chunk per row): every load of the wave's rows - x, dy, residual gradient - issued up front and kept as loaded, xhat and the
-// scaled gradient recomputed in the dx pass.  Measured 560 vs 660 us on 512 k x 512 rows; on D = 768 / 1024 it is 5-10 % slower
-// than the form above (tools/gpu_norm_bench.py), so the launcher picks by D.
-// eight elements as loaded (16 B of bf16 / 32 B of fp32): rows wait for their turn in this form, not as eight floats
-template <typename T> struct LnRaw8;
-template <> struct LnRaw8<bf16_t> {
-    uint4 u;
-    __device__ __forceinline__ void load(const bf16_t* p) { u = *reinterpret_cast<const uint4*>(p); }
-    __device__ __forceinline__ void zero() { u = make_uint4(0, 0, 0, 0); }
-    // opaque to the optimiser: conversions of this row happen after this point and are not shared with earlier ones
-    __device__ __forceinline__ void touch() { asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w)); }
-    __device__ __forceinline__ void get(float o[8]) const {
-        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
-        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
-        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
-        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
-    }
-};
-template <> struct LnRaw8<float> {
-    float4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
-    __device__ __forceinline__ void zero() { a = b = make_float4(0.f, 0.f, 0.f, 0.f); }
-    __device__ __forceinline__ void touch() {}
-    __device__ __forceinline__ void get(float o[8]) const { o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w; }
-};
-
-template <typename T, bool ACT>
-__global__ __launch_bounds__(256) void norm_bwd_fused_raw_kernel(SmxNormBwdParams p) {
-    __shared__ float red[4][64][8];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + w) * LN_PR;
-    const float invD = 1.0f / (float)p.D;
-    float dg[LN_NCH][8], db[LN_NCH][8], gm[LN_NCH][8], bt[LN_NCH][8];
-#pragma unroll
-    for (int j = 0; j < LN_NCH; ++j) {
-        const int c = (lane + 64 * j) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dg[j][e] = db[j][e] = gm[j][e] = bt[j][e] = 0.f;
-        if (c < p.D) {
-            load8(p.gamma + c, gm[j]);
-            if (ACT && p.beta) load8(p.beta + c, bt[j]);
-        }
-    }
-    // every load of the wave's LN_PR rows - x, dy and the residual-branch gradient - is issued up front and kept as loaded
-    // (the residual rows used to be requested inside the row loop, one exposed latency per row)
-    LnRaw8<T> xr[LN_PR][LN_NCH], dr[LN_PR][LN_NCH], rr[LN_PR][LN_NCH];
-    float mean[LN_PR], rstd[LN_PR];
-    const bool has_res = p.dres != nullptr;
-#pragma unroll
-    for (int r = 0; r < LN_PR; ++r) {
-        const int row = row0 + r;
-        mean[r] = 0.f; rstd[r] = 0.f;
-        if (row < p.M) {
-            mean[r] = p.rms ? 0.f : p.mean[row];
-            rstd[r] = p.rstd[row];
-        }
-#pragma unroll
-        for (int j = 0; j < LN_NCH; ++j) {
-            const int c = (lane + 64 * j) * 8;
-            xr[r][j].zero(); dr[r][j].zero(); rr[r][j].zero();
-            if (row < p.M && c < p.D) {
-                xr[r][j].load(reinterpret_cast<const T*>(p.x) + (long long)row * p.D + c);
-                dr[r][j].load(reinterpret_cast<const T*>(p.dy) + (long long)row * p.D + c);
-                if (has_res) rr[r][j].load(reinterpret_cast<const T*>(p.dres) + (long long)row * p.D + c);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < LN_PR; ++r) {
-        const int row = row0 + r;
-        float s1 = 0.f, s2 = 0.f;
-        // ACT: xhat and the scaled gradient are kept for the dx pass (the activation derivative is the expensive part);
-        // otherwise they are recomputed there from the raw rows, which keeps the kernel at three waves per SIMD
-        float xh[ACT ? LN_NCH : 1][8], gg[ACT ? LN_NCH : 1][8];
-        auto row_terms = [&](int j, int e, float xv, float dv, float& xhat, float& d) {
-            xhat = (xv - mean[r]) * rstd[r];
-            d = dv;
-            if (p.drop_p > 0.f)
-                d *= smx_drop_mul(p.drop_seed, (unsigned)(row * p.D + (lane + 64 * j) * 8 + e), smx_thresh24(p.drop_p),
-                                  1.0f / (1.0f - p.drop_p));
-            if (ACT) d *= act_grad(xhat * gm[j][e] + bt[j][e], p.act);
-        };
-#pragma unroll
-        for (int j = 0; j < LN_NCH; ++j) {
-            float xv[8], dv[8];
-            xr[r][j].touch(); dr[r][j].touch();
-            xr[r][j].get(xv);
-            dr[r][j].get(dv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float xhat, d;
-                row_terms(j, e, xv[e], dv[e], xhat, d);
-                dg[j][e] += d * xhat;
-                db[j][e] += d;
-                const float g = d * gm[j][e];
-                if (ACT) { xh[j][e] = xhat; gg[j][e] = g; }
-                s1 += g;
-                s2 += g * xhat;
-            }
-        }
-        s1 = p.rms ? 0.f : wave_sum(s1) * invD;
-        s2 = wave_sum(s2) * invD;
-        if (row < p.M) {
-            T* dx = reinterpret_cast<T*>(p.dx) + (long long)row * p.D;
-            float* dpos = p.dpos ? p.dpos + (long long)((row % p.pos_period) + p.pos_offset) * p.D : nullptr;
-#pragma unroll
-            for (int j = 0; j < LN_NCH; ++j) {
-                const int c = (lane + 64 * j) * 8;
-                if (c < p.D) {
-                    float o[8], res[8], xv[8], dv[8];
-                    rr[r][j].touch();
-                    rr[r][j].get(res);
-                    if (!ACT) { xr[r][j].touch(); dr[r][j].touch(); xr[r][j].get(xv); dr[r][j].get(dv); }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float xhat, g;
-                        if (ACT) { xhat = xh[j][e]; g = gg[j][e]; }
-                        else { float d; row_terms(j, e, xv[e], dv[e], xhat, d); g = d * gm[j][e]; }
-                        o[e] = (g - s1 - xhat * s2) * rstd[r];
-                        if (dpos) atomicAdd(dpos + c + e, o[e]);
-                        o[e] += res[e];                               // zeros without a residual branch
-                    }
-                    store8(dx + c, o);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < LN_NCH; ++j) {
-        if (64 * 8 * j >= p.D) break;
-        const int c = (lane + 64 * j) * 8;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[w][lane][e] = pass == 0 ? dg[j][e] : db[j][e];
-            __syncthreads();
-            if (w == 0 && c < p.D) {
-                float sum8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sum8[e] = red[0][lane][e] + red[1][lane][e] + red[2][lane][e] + red[3][lane][e];
-                store8(p.partials + ((long long)blockIdx.x * 2 + pass) * p.D + c, sum8);
             }
         }
     }
@@ -579,7 +438,32 @@ static int ln_rows_per_wave(int M) {
     static const int forced = getenv("SMX_NORM_PR") ? atoi(getenv("SMX_NORM_PR")) : 0;                 // A/B switch: 1 / 2 / 4
     if (!fuse) return LN_PR;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return M >= 32000 ? 4 : M >= 12000 ? 2 : M >= 4096 ? 4 : 1;      // measured (tools/gpu_norm_bench.py): 15 968 rows 32.9 vs 34.7 us (2 vs 4), 7 968 rows 21.3 vs 18.8, 1 024 rows 11.4 vs 12.8 (1 vs 4)
+    // one row per wave: with the blocks persistent over row groups (ln_grid) the per-block reduction no longer argues for more rows
+    // per block, and fewer registers keep three blocks per CU resident.  15 968 x 768: 26.1 us against 29.8 (2 rows, 512 blocks) and
+    // 59.7 (4 rows); 7 968 rows 16.7 vs 18.1; 511 968 x 512 (the CNN's layer norms, configs 4 / 5) 357 us against 486 / 518 and 560 for the
+    // raw-staged variant that round 2 used there
+    (void)M;
+    return 1;
+}
+
+// blocks of the fused backward = partial-row sets it leaves: one resident round of the chip (3 blocks per CU - the kernel's
+// launch bound - on every CU), each block walking the row groups; fewer when there are fewer groups.  Measured on 15 968 x 768
+// (tools/gpu_norm_bench.py, one row per wave): a block per group 41.1 us, 512 / 768 / 1024 / 1536 blocks 31.3 / 26.1 / 33.8 /
+// 29.3 us - whole rounds of resident blocks win, and one round is best.  SMX_NORM_GRID=n overrides (0: a block per group).
+static int ln_grid(int M, int pr) {
+    static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');
+    static const int forced = getenv("SMX_NORM_GRID") ? atoi(getenv("SMX_NORM_GRID")) : -1;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
+    }
+    const int cap = forced >= 0 ? forced : LN_BLOCKS_PER_CU * cus;
+    const int groups = (M + 4 * pr - 1) / (4 * pr);
+    return (fuse && cap > 0 && groups > cap) ? cap : groups;
 }
 
 extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t stream) {
@@ -594,11 +478,10 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     const bool act = p.act != SMX_ACT_NONE;
     dim3 grid((p.M + 3) / 4);
     static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');      // A/B switch
-    static const int raw_mode = getenv("SMX_NORM_RAW") ? atoi(getenv("SMX_NORM_RAW")) : -1;           // A/B switch: 0 / 1 force
     if (p.dx_drop && !fuse) return SMX_EINVAL;          // the third output exists in the fused kernel only
     if (fuse && (p.dgamma || p.dbeta)) {
         const int pr = ln_rows_per_wave(p.M);
-        const int blocks = (p.M + 4 * pr - 1) / (4 * pr);         // workspace: blocks * 2 (3) * D floats
+        const int blocks = ln_grid(p.M, pr);                     // workspace: blocks * 2 (3) * D floats
 #define LN_FUSED(T, A)                                                                                                  \
     do {                                                                                                                \
         if (pr == 4) hipLaunchKernelGGL((norm_bwd_fused_kernel<T, A, 4>), dim3(blocks), dim3(256), 0, stream, p);       \
@@ -607,9 +490,6 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     } while (0)
         if (dtype == SMX_F32) {
             if (act) LN_FUSED(float, true); else LN_FUSED(float, false);
-        } else if (pr == LN_PR && !p.dx_drop && (raw_mode == 1 || (raw_mode < 0 && p.D <= 512))) {      // narrow rows: see norm_bwd_fused_raw_kernel
-            if (act) hipLaunchKernelGGL((norm_bwd_fused_raw_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((norm_bwd_fused_raw_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, p);
         } else {
             if (act) LN_FUSED(bf16_t, true); else LN_FUSED(bf16_t, false);
         }
@@ -642,7 +522,7 @@ extern "C" int smx_norm_bwd(const SmxNormBwdParams* pp, int dtype, hipStream_t s
     SMX_CHECK_LAUNCH();
 }
 
-extern "C" int smx_norm_bwd_partial_rows(int M) { const int pr = ln_rows_per_wave(M); return (M + 4 * pr - 1) / (4 * pr); }
+extern "C" int smx_norm_bwd_partial_rows(int M) { return ln_grid(M, ln_rows_per_wave(M)); }
 
 // ABI self-description (checked by the ctypes binding against its struct mirrors)
 extern "C" int smx_sizeof_SmxNormParams(void) { return (int)sizeof(SmxNormParams); }

@@ -21,6 +21,13 @@ for M, D, res, act in ((15968, 768, True, 0), (7968, 768, True, 0), (1024, 768, 
         ops.norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dg, db, M, D, ops.BF16, dres=dres, folds=folds, act=act)
         folds.items.clear()
     tb = bench(bw, n=30)
+    t3 = float("nan")
+    if not act and res:          # the post-LN fused site: dx x dropout mask of the producing Linear + its bias-gradient partial row
+        dxd = torch.empty_like(x); gb2 = torch.zeros(D, device=dev)
+        def bw3():
+            ops.norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dg, db, M, D, ops.BF16, dres=dres, folds=folds, drop2=(0.1, 7), dx_drop=dxd, gb2=gb2)
+            folds.items.clear()
+        t3 = bench(bw3, n=30)
     # reference
     dg.zero_(); db.zero_()
     ops.norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dg, db, M, D, ops.BF16, dres=dres, folds=folds, act=act); folds.flush()
@@ -40,4 +47,4 @@ for M, D, res, act in ((15968, 768, True, 0), (7968, 768, True, 0), (1024, 768, 
         eb = ((db - dy.float().sum(0)).abs().max() / db.abs().max()).item()
     by_f = M * D * 2 * 2; by_b = M * D * 2 * (4 if res else 3)
     print(f"M={M} D={D} dres={res} act={act}: fwd {tf:.1f} us ({by_f / tf / 1e6:.2f} TB/s) | bwd {tb:.1f} us ({by_b / tb / 1e6:.2f} TB/s) | "
-          f"dx rel err {err:.2e} dgamma {eg:.2e} dbeta {eb:.2e}", flush=True)
+          f"with masked-dx output {t3:.1f} us ({M * D * 2 * 5 / t3 / 1e6 if t3 == t3 else 0:.2f} TB/s) | dx rel err {err:.2e} dgamma {eg:.2e} dbeta {eb:.2e}", flush=True)
