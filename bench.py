@@ -188,8 +188,8 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)          # >= 5 warm-up + >= 20 timed steps
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--optimizer", default="adafactor", choices=["adafactor", "adamw"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
