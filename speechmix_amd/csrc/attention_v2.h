@@ -13,12 +13,38 @@
 //     a score costs one v_bfe_i32 + one v_and_b32; the 1/(1-p) scale is folded into the output scales;
 //   * the running row sum is kept per lane and reduced across the four lane groups once, after the last tile.
 #pragma once
+#include <utility>
 
 #define A2_QW(T) ((((T) + 63) >> 6) << 1)          // 32-bit mask words per row: whole 64-wide tiles
 
 // ---------------------------------------------------------------- dropout bit masks
 // wave = 64 queries x one 32-key word; keep(q, k) <=> hash field of index rowbase(q) + k >= threshold - exactly
 // smx_drop_mul's decision (rowbase % 4 == 0: the index parity is the key's).
+template <int LANE>
+__device__ __forceinline__ void a2_writelane(unsigned& v, unsigned s) {       // v[LANE] = s (wave-uniform s)
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+}
+// keys kw * 32 + 2 J, + 1 of my query: one hash, two compares; a compare's result IS the 64-query bit column of its key
+template <int J>
+__device__ __forceinline__ void a2_mask_pair(const SmxAttnParams& p, int kw, unsigned rb, unsigned th, bool qok, unsigned& w,
+                                             unsigned& mine_lo, unsigned& mine_hi) {
+    const int key = kw * 32 + 2 * J;
+    const unsigned hsh = smx_hash32(p.drop_seed, (rb + (unsigned)key) >> 1);
+    const bool k0 = qok && key < p.Tk && (hsh & 0xffffu) >= th;
+    const bool k1 = qok && key + 1 < p.Tk && (hsh >> 16) >= th;
+    if (k0) w |= 1u << (2 * J);
+    if (k1) w |= 2u << (2 * J);
+    const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1);
+    a2_writelane<2 * J>(mine_lo, (unsigned)b0);
+    a2_writelane<2 * J>(mine_hi, (unsigned)(b0 >> 32));
+    a2_writelane<2 * J + 1>(mine_lo, (unsigned)b1);
+    a2_writelane<2 * J + 1>(mine_hi, (unsigned)(b1 >> 32));
+}
+template <int... Js>
+__device__ __forceinline__ void a2_mask_pairs(std::integer_sequence<int, Js...>, const SmxAttnParams& p, int kw, unsigned rb, unsigned th,
+                                              bool qok, unsigned& w, unsigned& mine_lo, unsigned& mine_hi) {
+    (a2_mask_pair<Js>(p, kw, rb, th, qok, w, mine_lo, mine_hi), ...);
+}
 __global__ __launch_bounds__(256) void attn_mask_kernel(SmxAttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int KW = A2_QW(p.Tk), QW = A2_QW(p.Tq);
@@ -28,29 +54,18 @@ __global__ __launch_bounds__(256) void attn_mask_kernel(SmxAttnParams p) {
     if (kw >= KW) return;
     const int q = qb * 64 + lane;
     const unsigned th = smx_thresh24(p.drop_p) >> 8;
-    unsigned w = 0;
-    if (q < p.Tq) {
-        const unsigned rb = (unsigned)(((long long)bh * p.Tq + q) * (long long)((p.Tk + 3) & ~3));
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int key = kw * 32 + 2 * j;
-            const unsigned hsh = smx_hash32(p.drop_seed, (rb + (unsigned)key) >> 1);
-            if (key < p.Tk && (hsh & 0xffffu) >= th) w |= 1u << (2 * j);
-            if (key + 1 < p.Tk && (hsh >> 16) >= th) w |= 2u << (2 * j);
-        }
-        p.mask_q[((long long)bh * p.Tq + q) * KW + kw] = w;
-    }
-    unsigned long long mine = 0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const unsigned long long bal = __ballot((w >> j) & 1u);
-        if (lane == j) mine = bal;
-    }
+    const bool qok = q < p.Tq;
+    const unsigned rb = (unsigned)(((long long)bh * p.Tq + (qok ? q : 0)) * (long long)((p.Tk + 3) & ~3));
+    // The key-major words come straight from the compares' lane masks (two v_writelane_b32 per key into lane `key`); the round-2
+    // form re-derived every column from the finished query-major word: 32 x (bit extract, compare, lane compare, two selects).
+    unsigned w = 0, mine_lo = 0, mine_hi = 0;
+    a2_mask_pairs(std::make_integer_sequence<int, 16>{}, p, kw, rb, th, qok, w, mine_lo, mine_hi);
+    if (qok) p.mask_q[((long long)bh * p.Tq + q) * KW + kw] = w;
     const int key = kw * 32 + lane;
     if (lane < 32 && key < p.Tk) {
         unsigned* dst = p.mask_k + ((long long)bh * p.Tk + key) * QW + 2 * qb;
-        dst[0] = (unsigned)mine;
-        dst[1] = (unsigned)(mine >> 32);
+        dst[0] = mine_lo;
+        dst[1] = mine_hi;
     }
 }
 
@@ -77,13 +92,26 @@ __device__ __forceinline__ void a2_decode(const SmxAttnParams& p, int nx, int& b
 
 // max over the four 16-lane rows (same lane & 15) without the LDS crossbar: v_permlane16_swap / v_permlane32_swap exchange
 // row pairs / wave halves at VALU rate (the ds_bpermute pair of __shfl_xor sat on the per-tile critical path)
+// fmaxf() on values hipcc cannot prove canonical (MFMA results, permlane results) costs TWO instructions each - a self-max that
+// quiets signalling NaNs, then the max: 28 v_max_f32 per 64-key tile for the row maximum of 16 scores.  Scores are never NaN
+// here (masked ones are -inf), so the maxima go through the instructions directly: 8 x v_max3_f32 + 3 x v_max_f32.
+__device__ __forceinline__ float a2_max(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float a2_max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ float a2_group_max(float v) {
     const unsigned u = __float_as_uint(v);
     auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float a = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const float a = a2_max(__uint_as_float(r[0]), __uint_as_float(r[1]));
     const unsigned ua = __float_as_uint(a);
     auto r2 = __builtin_amdgcn_permlane32_swap(ua, ua, false, false);
-    return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+    return a2_max(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
 }
 
 // all-ones / all-zeros lane masks of the 4 scores a lane holds in 16-key block t of a 64-wide tile
@@ -140,11 +168,16 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
                 if (key >= tk || (CAUSAL && key > q + coff)) s[t][r] = -INFINITY;
             }
     }
-    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
-#pragma unroll
-    for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+    float mx = a2_max3(s[0][0], s[0][1], s[0][2]);
+    mx = a2_max3(mx, s[0][3], s[1][0]);
+    mx = a2_max3(mx, s[1][1], s[1][2]);
+    mx = a2_max3(mx, s[1][3], s[2][0]);
+    mx = a2_max3(mx, s[2][1], s[2][2]);
+    mx = a2_max3(mx, s[2][3], s[3][0]);
+    mx = a2_max3(mx, s[3][1], s[3][2]);
+    mx = a2_max(mx, s[3][3]);
     mx = a2_group_max(mx);
-    const float mn = fmaxf(m, mx * mul);
+    const float mn = a2_max(m, mx * mul);
     const float alpha = fast_exp2(m - mn);
     float rs = 0.f;
 #pragma unroll
