@@ -284,6 +284,17 @@ static inline int pp_epi_class(const SmxGemmParams& p) {
     return PP_EPI_LINEAR;
 }
 
+// SMX_ACT_SAVE_GRAD launches the 256-wide kernels accept (round 3): the two classes that carry the saved local derivative, on
+// aligned views only (their generic row epilogue does not know the flag) - forward ACT of a (KC, KC) launch, ACTGRAD of a
+// bias-free (KC, RC) data gradient
+static inline bool smx_epi_views_aligned(const SmxGemmParams& p);
+static inline bool pp_saved_ok(const SmxGemmParams& p) {
+    if (!(p.act & SMX_ACT_SAVE_GRAD)) return true;
+    if (p.a_rc || !smx_epi_views_aligned(p) || p.atomic || p.out_f32) return false;
+    const int epi = pp_epi_class(p);
+    return (!p.b_rc && epi == PP_EPI_ACT) || (p.b_rc && epi == PP_EPI_ACTGRAD && !p.bias);
+}
+
 // the specialised epilogues use 16-B accesses on every view: all strides / offsets multiples of 8 elements, N % 8 == 0
 static inline bool smx_epi_views_aligned(const SmxGemmParams& p) {
     const long long m = p.c.ld | p.c.off | p.c.batch_stride | p.e.ld | p.e.off | p.e.batch_stride | p.batch_c | p.batch_e |

@@ -239,7 +239,7 @@ int smx_gemm_pp(const SmxGemmParams& p, hipStream_t stream);   // gemm_pp.hip
 int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
     SmxGemmParams p = pin;
     const int mt = (p.tr_mode & 255) == 13 ? 192 : PP_BM;
-    if (p.act & SMX_ACT_SAVE_GRAD) return SMX_EINVAL;
+    if (!pp_saved_ok(p)) return SMX_EINVAL;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;

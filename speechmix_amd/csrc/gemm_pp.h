@@ -421,6 +421,11 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
     const float rrc = 1.0f / (float)max(p.c.rows_per_batch, 1), rre = 1.0f / (float)max(p.e.rows_per_batch, 1);
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
+    // SMX_ACT_SAVE_GRAD (round 3): the side tensor holds the epilogue's local derivative act'(pre) x dropout multiplier - written by
+    // the forward ACT class in place of the pre-activation copy, multiplied in by the data gradient's ACTGRAD class (no
+    // activation derivative, no mask regeneration there); same arithmetic as epilogue_staged_fast<4 / 5> of the 128-family kernels
+    const bool saved = (EPI == PP_EPI_ACT || EPI == PP_EPI_ACTGRAD) && (p.act & SMX_ACT_SAVE_GRAD);
+    const int act = p.act & 0xff;
     constexpr int GA = (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || NB % 4) ? 2 : 4;   // row blocks per group (x 2 halves = pieces in registers at once)
 #pragma unroll
     for (int grp = 0; grp < NB / GA; ++grp) {
@@ -499,17 +504,26 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                     continue;
                 }
                 if (EPI == PP_EPI_ACT) {
-                    auxv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
-                    act_fwd8(x, p.act);
+                    if (saved) {
+                        auxv[a][ch] = act_fwd_grad_drop8(x, act, drop, p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
+                    } else {
+                        auxv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
+                        act_fwd8(x, act);
+                    }
                 }
                 if (EPI == PP_EPI_ACTGRAD) {
                     const uint4 u = side[a][ch];
                     float s[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                                   __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
                                   __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
-                    act_grad_mul8(x, s, p.act);
+                    if (saved) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) x[e] *= s[e];
+                    } else {
+                        act_grad_mul8(x, s, act);
+                    }
                 }
-                if (drop) {
+                if (drop && !saved) {
                     const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
                     smx_drop_mul8(p.drop_seed, idx, th, inv_keep, x);        // idx % 8 == 0 (aligned views, N % 8 == 0)
                 }

@@ -216,7 +216,7 @@ static void pp_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
 
 int smx_gemm_pp(const SmxGemmParams& pin, hipStream_t stream) {
     SmxGemmParams p = pin;
-    if (p.act & SMX_ACT_SAVE_GRAD) return SMX_EINVAL;      // saved-derivative side tensors: 128x128 kernels only
+    if (!pp_saved_ok(p)) return SMX_EINVAL;                // saved-derivative side tensors: the two fast classes only
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;

@@ -139,7 +139,12 @@ ACT_SAVE_GRAD = 0x100     # SMX_ACT_SAVE_GRAD: the GEMM's side tensor holds the 
 
 def _pp_applicable(p, dtype):
     if p.act & ACT_SAVE_GRAD:
-        return False
+        # saved-derivative side tensors: the forward ACT class of a (KC, KC) launch and the bias-free ACTGRAD class of a (KC, RC)
+        # data gradient, aligned views only (csrc/gemm_common.h pp_saved_ok)
+        if p.a_rc or p.atomic or p.out_f32 or p.resid or (p.N & 7) or ((p.c.ld | p.c.off | p.e.ld | p.e.off) & 7):
+            return False
+        if not ((not p.b_rc and not p.aux_in) or (p.b_rc and p.aux_in and not p.aux_out and not p.bias)):
+            return False
     if dtype != BF16 or p.atomic == 1 or p.M < 256 or p.N < 64 or max(p.M, p.N, p.K) >= (1 << 22):
         return False
     if (p.K & 7) and not (p.a_rc and p.b_rc):

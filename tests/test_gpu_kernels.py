@@ -420,6 +420,49 @@ def test_half_height_tiles_of_the_128_kernel_are_bit_identical_to_it():
                  ops.BF16, out_f32=True, tr_mode=9)
 
 
+def test_saved_derivative_epilogues_of_the_256_wide_kernels_match_the_128_kernel():
+    """SMX_ACT_SAVE_GRAD on the ping-pong / free-running kernels (tr_mode 8, 12, 13; round 3): forward ACT writes
+    act(pre) x mask and the local derivative act'(pre) x mask, the data gradient multiplies by the saved derivative.  Same
+    arithmetic as the 128-family epilogues (epilogue_staged_fast<4 / 5>) on the same fp32 accumulators (same K order): bit for
+    bit, with and without dropout, GELU and ReLU, ragged M; unsupported combinations are refused."""
+    import torch
+    from speechmix_amd import ops
+    from speechmix_amd.ops import ACT_GELU, ACT_RELU, view
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    for (M, N, K) in ((15968, 3072, 768), (4000, 768, 256), (1000, 1024, 192)):
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        Wt = W.t().contiguous()
+        bias = torch.randn(N, device=dev) * 0.1
+        S = torch.randn(M, N, device=dev).bfloat16()
+        for act in (ACT_GELU, ACT_RELU):
+            for drop in (None, (0.1, 11)):
+                ref = None
+                for mode in (1, 8, 12, 13):
+                    Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                    aux = torch.zeros_like(Y)
+                    ops.gemm(A, W, Y, M, N, K, ops.BF16, bias=bias, act=act | ops.ACT_SAVE_GRAD, aux_out=aux, drop=drop, tr_mode=mode)
+                    D = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                    ops.gemm(A, Wt, D, M, N, K, ops.BF16, b_rc=True, bv=view(N), aux_in=S, act=act | ops.ACT_SAVE_GRAD, tr_mode=mode)
+                    if ref is None:
+                        ref = (Y, aux, D)
+                        assert Y.float().abs().max().item() > 0 and aux.float().abs().max().item() > 0
+                        continue
+                    assert torch.equal(ref[0], Y), ("out", M, N, K, act, drop, mode)
+                    assert torch.equal(ref[1], aux), ("derivative", M, N, K, act, drop, mode)
+                    assert torch.equal(ref[2], D), ("dgrad", M, N, K, act, drop, mode)
+    M, N, K = 1024, 512, 256
+    A = torch.zeros(M, K, device=dev).bfloat16(); W = torch.zeros(N, K, device=dev).bfloat16()
+    Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    for mode in (8, 12):
+        with pytest.raises(RuntimeError):          # a data gradient with a bias has no saved-derivative class
+            ops.gemm(A, W.t().contiguous(), Y, M, N, K, ops.BF16, b_rc=True, bv=view(N), aux_in=Y, bias=torch.zeros(N, device=dev),
+                     act=ACT_GELU | ops.ACT_SAVE_GRAD, tr_mode=mode)
+        with pytest.raises(RuntimeError):          # residual + saved derivative: generic epilogue, not available
+            ops.gemm(A, W, Y, M, N, K, ops.BF16, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out=torch.zeros_like(Y), resid=torch.zeros_like(Y), tr_mode=mode)
+
+
 @pytest.mark.parametrize("V", [50265, 130, 64])
 def test_cross_entropy_two_pass_kernel_matches_torch(V):
     """loss (mean over valid tokens, ignore_index -100), first arg max and d loss / d logits of the vectorised two-pass kernel."""
