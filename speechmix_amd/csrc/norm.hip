@@ -11,6 +11,8 @@
 
 #define LN_NCH 2  // 8-element chunks per lane -> D <= 64 * 8 * 2
 #define LN_BLOCKS_PER_CU 3   // resident blocks per CU of the fused backward (its launch bound)
+#define LN_FWD_BLOCKS_PER_CU 6   // ... of the forward (its launch bound).  15 968 x 768: 15.9 us with a block per four rows, 14.0 us with 1 536 persistent
+                                 // blocks (768 / 1 024 / 2 048 / 3 072: 19.9 / 16.5 / 16.6 / 15.0); 511 968 x 512: 315 -> 257 us
 
 struct SmxNormParams {
     const void* x;        // [M, D] input (dtype T)
@@ -30,73 +32,85 @@ struct SmxNormParams {
     unsigned drop_seed;
 };
 
+// One wave per row, blocks persistent over the rows (grid = one resident round of the chip, smx_norm_fwd): gamma / beta are
+// loaded once per wave instead of once per row, and a wave's next row is requested while it finishes the current one.
 template <typename T>
-__global__ __launch_bounds__(256) void norm_fwd_kernel(SmxNormParams p) {
+__global__ __launch_bounds__(256, LN_FWD_BLOCKS_PER_CU) void norm_fwd_kernel(SmxNormParams p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    const T* x = reinterpret_cast<const T*>(p.x) + (long long)row * p.D;
-    const T* pos = p.pos ? reinterpret_cast<const T*>(p.pos) + (long long)((row % p.pos_period) + p.pos_offset) * p.D
-                         : nullptr;
-    T* xs = p.xsum_out ? reinterpret_cast<T*>(p.xsum_out) + (long long)row * p.D : nullptr;
-    float v[LN_NCH][8];
-    float s = 0.f;
+    float gm[LN_NCH][8], bt[LN_NCH][8];
 #pragma unroll
     for (int j = 0; j < LN_NCH; ++j) {
         const int c = (lane + 64 * j) * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        for (int e = 0; e < 8; ++e) { gm[j][e] = 0.f; bt[j][e] = 0.f; }
         if (c < p.D) {
-            load8(x + c, v[j]);
-            if (pos) {
-                float t[8];
-                load8(pos + c, t);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[j][e] = rt(v[j][e] + t[e], x);
-            }
-            if (xs) store8(xs + c, v[j]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[j][e];
+            load8(p.gamma + c, gm[j]);
+            if (p.beta) load8(p.beta + c, bt[j]);
         }
     }
     const float invD = 1.0f / (float)p.D;
-    float mean = 0.f;
-    if (!p.rms) mean = wave_sum(s) * invD;
-    float q = 0.f;
+    const unsigned th = smx_thresh24(p.drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < p.M; row += gridDim.x * 4) {
+        const T* x = reinterpret_cast<const T*>(p.x) + (long long)row * p.D;
+        const T* pos = p.pos ? reinterpret_cast<const T*>(p.pos) + (long long)((row % p.pos_period) + p.pos_offset) * p.D
+                             : nullptr;
+        T* xs = p.xsum_out ? reinterpret_cast<T*>(p.xsum_out) + (long long)row * p.D : nullptr;
+        float v[LN_NCH][8];
+        float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_NCH; ++j) {
-        const int c = (lane + 64 * j) * 8;
-        if (c < p.D) {
+        for (int j = 0; j < LN_NCH; ++j) {
+            const int c = (lane + 64 * j) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float d = v[j][e] - mean;
-                q += d * d;
+            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+            if (c < p.D) {
+                load8(x + c, v[j]);
+                if (pos) {
+                    float t[8];
+                    load8(pos + c, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[j][e] = rt(v[j][e] + t[e], x);
+                }
+                if (xs) store8(xs + c, v[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[j][e];
             }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(q) * invD + p.eps);
-    if (lane == 0) {
-        if (p.mean) p.mean[row] = mean;
-        if (p.rstd) p.rstd[row] = rstd;
-    }
-    T* y = reinterpret_cast<T*>(p.y) + (long long)row * p.D;
+        float mean = 0.f;
+        if (!p.rms) mean = wave_sum(s) * invD;
+        float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_NCH; ++j) {
-        const int c = (lane + 64 * j) * 8;
-        if (c < p.D) {
-            float o[8], gm[8], bt[8];
-            load8(p.gamma + c, gm);
-            if (p.beta) load8(p.beta + c, bt);
+        for (int j = 0; j < LN_NCH; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            if (c < p.D) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = (v[j][e] - mean) * rstd * gm[e];
-                if (p.beta) t += bt[e];
-                t = act_fwd(t, p.act);
-                if (p.drop_p > 0.f)
-                    t *= smx_drop_mul(p.drop_seed, (unsigned)(row * p.D + c + e), smx_thresh24(p.drop_p), 1.0f / (1.0f - p.drop_p));
-                o[e] = t;
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[j][e] - mean;
+                    q += d * d;
+                }
             }
-            store8(y + c, o);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invD + p.eps);
+        if (lane == 0) {
+            if (p.mean) p.mean[row] = mean;
+            if (p.rstd) p.rstd[row] = rstd;
+        }
+        T* y = reinterpret_cast<T*>(p.y) + (long long)row * p.D;
+#pragma unroll
+        for (int j = 0; j < LN_NCH; ++j) {
+            const int c = (lane + 64 * j) * 8;
+            if (c < p.D) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = (v[j][e] - mean) * rstd * gm[j][e];
+                    if (p.beta) t += bt[j][e];
+                    t = act_fwd(t, p.act);
+                    if (p.drop_p > 0.f) t *= smx_drop_mul(p.drop_seed, (unsigned)(row * p.D + c + e), th, inv_keep);
+                    o[e] = t;
+                }
+                store8(y + c, o);
+            }
         }
     }
 }
@@ -420,12 +434,28 @@ __global__ void norm_bwd_finalize_kernel(const float* __restrict__ partials, int
     if (dbeta) atomicAdd(dbeta + c, b);
 }
 
+static int ln_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+        (void)hipGetLastError();
+    }
+    return cus;
+}
+
 extern "C" int smx_norm_fwd(const SmxNormParams* pp, int dtype, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
     SmxNormParams p = *pp;
     if (p.M <= 0 || p.D <= 0 || p.D > 64 * 8 * LN_NCH || (p.D & 7)) return SMX_EINVAL;
     if (p.pos && p.pos_period <= 0) return SMX_EINVAL;
-    dim3 grid((p.M + 3) / 4);
+    // one resident round: LN_FWD_BLOCKS_PER_CU blocks on every CU (SMX_NORMF_GRID=n overrides, 0: a block per four rows)
+    static const int forced = getenv("SMX_NORMF_GRID") ? atoi(getenv("SMX_NORMF_GRID")) : -1;
+    const int cap = forced >= 0 ? forced : LN_FWD_BLOCKS_PER_CU * ln_cus();
+    const int blocks = (p.M + 3) / 4;
+    dim3 grid(cap > 0 && blocks > cap ? cap : blocks);
     if (dtype == SMX_F32) hipLaunchKernelGGL(norm_fwd_kernel<float>, grid, dim3(256), 0, stream, p);
     else if (dtype == SMX_BF16) hipLaunchKernelGGL(norm_fwd_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
     else return SMX_EINVAL;
@@ -453,15 +483,7 @@ static int ln_rows_per_wave(int M) {
 static int ln_grid(int M, int pr) {
     static const bool fuse = !(getenv("SMX_NORM_FUSED") && getenv("SMX_NORM_FUSED")[0] == '0');
     static const int forced = getenv("SMX_NORM_GRID") ? atoi(getenv("SMX_NORM_GRID")) : -1;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-        (void)hipGetLastError();
-    }
-    const int cap = forced >= 0 ? forced : LN_BLOCKS_PER_CU * cus;
+    const int cap = forced >= 0 ? forced : LN_BLOCKS_PER_CU * ln_cus();
     const int groups = (M + 4 * pr - 1) / (4 * pr);
     return (fuse && cap > 0 && groups > cap) ? cap : groups;
 }
