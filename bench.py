@@ -216,10 +216,18 @@ def main():
         print(json.dumps({"spawn_check": True, "rank": rank, "world": world, "gpus": args.gpus, "rank_sum": t.item()}), flush=True)
         dist.destroy_process_group()
         return
+    # SMX_BENCH_SHARED_GPU=1 (tests/test_gpu_r3.py): every rank on cuda:0 over gloo - the N > 1 logic (stage buckets on the side
+    # stream, pick broadcast, CU reserve, max-over-ranks timing) on the real kernels of a 1-GPU box; not a measurement
+    shared = os.environ.get("SMX_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from speechmix_amd import ops
@@ -238,7 +246,8 @@ def main():
         np.random.seed(args.seed + rank)
         torch.manual_seed(args.seed + rank)
     # optimizer: the reference trains with HF Trainer's optim="adafactor", lr 5e-4 (ref:train.py:298, 305); AdamW kept as a switch
-    runner = StepRunner(model, lr=5e-4 if args.optimizer == "adafactor" else 4e-5, optimizer=args.optimizer, max_grad_norm=1.0)
+    runner = StepRunner(model, lr=5e-4 if args.optimizer == "adafactor" else 4e-5, optimizer=args.optimizer,
+                        max_grad_norm=float(os.environ.get("SMX_BENCH_CLIP", "1.0")))      # (0: no global-norm clip - A/B hook)
     B = args.batch
     wave, labels = synth_batch(B, model.decoder_model.config.vocab_size, rank, device)
 
@@ -272,6 +281,13 @@ def main():
         if world > 1:
             dist.barrier()
     final_loss = float(loss.item())
+    in_sync = None
+    if world > 1 and os.environ.get("SMX_BENCH_CHECK_SYNC") == "1":
+        # data-parallel replicas must hold bit-identical parameters after every step (same reduced gradients, same update)
+        h = model.store.master.view(torch.int32).to(torch.int64).sum().reshape(1)
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(hs, h)
+        in_sync = all(int(x.item()) == int(hs[0].item()) for x in hs)
     # p = 0 leg ("report both p=0 and reference-default p"): the same K steps with dropout, LayerDrop and
     # SpecAugment off, timed the same way; reported beside `value`, never instead of it
     eval_ms = None
@@ -307,10 +323,12 @@ def main():
                 "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "SpeechMixEED wav2vec2-base + bart-base, 32 x 10 s clips/GPU, down_scale=2, "
+                "config": {"workload": f"SpeechMixEED wav2vec2-base + bart-base, {B} x 10 s clips/GPU, down_scale=2, "
                                        "32 label tokens, fwd+bwd+allreduce+clip+" + {"adafactor": "Adafactor", "adamw": "AdamW"}[args.optimizer] + ", " + mode,
                            "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
                 "final_loss": round(final_loss, 4)}
+        if in_sync is not None:
+            line["params_in_sync"] = in_sync
         if eval_ms is not None:
             line["eval_mode"] = {"ms_per_step": round(eval_ms, 3), "value": round(world * B * CLIP_SECONDS / (eval_ms * 1e-3), 1),
                                  "note": "p = 0: dropout / LayerDrop / SpecAugment off, all 12 encoder layers every step"}

@@ -199,12 +199,15 @@ int smx_optimizer_step(const SmxOptParams* p, hipStream_t stream);
 /* Adafactor over the flat buffer: the optimizer the reference trains with (ref:train.py:298 optim="adafactor" -> HF
  * Trainer: transformers.optimization.Adafactor(lr, scale_parameter=False, relative_step=False)); replaces the per-tensor
  * loop of TF:optimization.py Adafactor.step.  Work lists are built by the caller (speechmix_amd/ops.py AdafactorPlan). */
-typedef struct SmxAfTensor { long long off; int nb, R, C, row_off, col_off, rm_off, factored, _pad; } SmxAfTensor;
-typedef struct SmxAfTile { int tensor, b, r0, nr, c0, nc, full_rows, full_cols; } SmxAfTile;
-typedef struct SmxAfSeg { int tensor, b; } SmxAfSeg;
+/* Every reduction of the step runs in a fixed order (no order-dependent fp32 atomics): data-parallel replicas that apply it to the
+ * same all-reduced gradients keep bit-identical parameters.  tile0 / ntile: a tensor's (contiguous) tiles; cp_off / rp_off: where a
+ * tile's column partials / row sums go in `cpart` ([row tiles][C] and [column tiles][R] blocks per (tensor, leading index)). */
+typedef struct SmxAfTensor { long long off; int nb, R, C, row_off, col_off, rm_off, factored, tile0, ntile, _pad; } SmxAfTensor;
+typedef struct SmxAfTile { int tensor, b, r0, nr, c0, nc, full_rows, full_cols, cp_off, rp_off; } SmxAfTile;
+typedef struct SmxAfSeg { int tensor, b, cp_off, n_rt, rp_off, n_ct; } SmxAfSeg;
 typedef struct SmxAfParams {
     float* p; const float* g; void* shadow; const SmxAfTensor* tensors; const SmxAfTile* tiles; const SmxAfSeg* segs;
-    float *row, *col, *racc, *cacc, *rmean, *usq; const float* beta2t; const float* gnorm_sq;
+    float *row, *col, *racc, *cacc, *rmean, *usq, *usq_part, *cpart; const float* beta2t; const float* gnorm_sq;
     long long racc_n, cacc_n; int ntensors, ntiles, nsegs;
     float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
 } SmxAfParams;
@@ -236,6 +239,7 @@ int smx_sizeof_SmxWsumParams(void);
 int smx_sizeof_SmxAfParams(void);
 int smx_sizeof_SmxAfTensor(void);
 int smx_sizeof_SmxAfTile(void);
+int smx_sizeof_SmxAfSeg(void);
 
 #ifdef __cplusplus
 }

@@ -119,18 +119,24 @@ class OptParams(C.Structure):
 
 class AfTensor(C.Structure):
     _fields_ = [("off", C.c_longlong), ("nb", C.c_int), ("R", C.c_int), ("C", C.c_int), ("row_off", C.c_int),
-                ("col_off", C.c_int), ("rm_off", C.c_int), ("factored", C.c_int), ("_pad", C.c_int)]
+                ("col_off", C.c_int), ("rm_off", C.c_int), ("factored", C.c_int), ("tile0", C.c_int), ("ntile", C.c_int),
+                ("_pad", C.c_int)]
 
 
 class AfTile(C.Structure):
     _fields_ = [("tensor", C.c_int), ("b", C.c_int), ("r0", C.c_int), ("nr", C.c_int), ("c0", C.c_int), ("nc", C.c_int),
-                ("full_rows", C.c_int), ("full_cols", C.c_int)]
+                ("full_rows", C.c_int), ("full_cols", C.c_int), ("cp_off", C.c_int), ("rp_off", C.c_int)]
+
+
+class AfSeg(C.Structure):
+    _fields_ = [("tensor", C.c_int), ("b", C.c_int), ("cp_off", C.c_int), ("n_rt", C.c_int), ("rp_off", C.c_int), ("n_ct", C.c_int)]
 
 
 class AfParams(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("shadow", C.c_void_p), ("tensors", C.c_void_p), ("tiles", C.c_void_p),
                 ("segs", C.c_void_p), ("row", C.c_void_p), ("col", C.c_void_p), ("racc", C.c_void_p), ("cacc", C.c_void_p),
-                ("rmean", C.c_void_p), ("usq", C.c_void_p), ("beta2t", C.c_void_p), ("gnorm_sq", C.c_void_p),
+                ("rmean", C.c_void_p), ("usq", C.c_void_p), ("usq_part", C.c_void_p), ("cpart", C.c_void_p), ("beta2t", C.c_void_p),
+                ("gnorm_sq", C.c_void_p),
                 ("racc_n", C.c_longlong), ("cacc_n", C.c_longlong), ("ntensors", C.c_int), ("ntiles", C.c_int),
                 ("nsegs", C.c_int), ("lr", C.c_float), ("eps1", C.c_float), ("clip_threshold", C.c_float),
                 ("grad_scale", C.c_float), ("max_grad_norm", C.c_float)]

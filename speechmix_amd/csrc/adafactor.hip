@@ -7,12 +7,19 @@
 //     upd /= max(1, rms(upd) / clip_threshold) ;  p -= lr upd           beta2t = 1 - step^decay_rate
 // The state is two vectors per matrix instead of AdamW's two full copies (2 MB instead of 1.9 GB at config 2).
 //
-// One step = a memset + four launches over host-built work lists (no per-tensor launches: 458 tensors at config 2):
-//   stats   tiles of <= 64 rows x <= 2048 columns: row sums by wave reductions, column partials in registers, one
-//           atomic per row / column only where a tile does not cover the whole row / column range
+// One step = a memset + five launches over host-built work lists (no per-tensor launches: 458 tensors at config 2):
+//   stats   tiles of >= 64 rows x <= 2048 columns: row sums by wave reductions, column partials in registers
 //   fold    one block per (tensor, leading index): the two moving averages, the row mean
-//   rms     tiles again: sum upd^2 per tensor          apply   tiles again: the update + the bf16 compute copy
+//   rms     tiles again: sum upd^2 per tile     usq   per tensor     apply   tiles again: the update + the bf16 compute copy
 // Gradient traffic 3 x 4 B + parameters 8 B + bf16 copy 2 B = 22 B / parameter (AdamW: 30).
+//
+// EVERY reduction has a fixed order (round 3).  Data-parallel replicas apply this update to identical all-reduced gradients and
+// must end with identical parameters; with fp32 atomics summing the column partials of a matrix's row tiles and the per-tile
+// sum upd^2 in arrival order, two ranks drifted apart bit-wise within four steps (tests/test_gpu_r3.py, two ranks on one GPU).
+// Now a row tile stores its column partials into its own row of a scratch matrix [row tiles][C] that the fold sums in tile
+// order, a tile stores its sum upd^2 into its own slot and one thread per tensor adds the slots in tile order; the only
+// atomics left are the row sums of matrices wider than one column tile, which receive exactly two commutative additions
+// onto zero (the host plan refuses C > 2 * AF_MAXC).
 #include "smx_common.h"
 
 struct SmxAfTensor {
@@ -21,14 +28,18 @@ struct SmxAfTensor {
     int row_off, col_off; // offsets into row / col state (factored) ; vec_off = col_off for 1-D tensors (state v)
     int rm_off;           // offset into the per-(tensor, batch) row-mean array
     int factored;
+    int tile0, ntile;     // this tensor's tiles in the tile list (contiguous)
     int _pad;
 };
 struct SmxAfTile {
     int tensor, b, r0, nr, c0, nc;
     int full_rows;        // tile spans every column: row sums are final (plain store)
     int full_cols;        // tile spans every row: column sums are final
+    int cp_off;           // !full_cols: where this tile's nc column partials go in `cpart` (segment base + row tile * C + c0)
+    int rp_off;           // !full_rows: where this tile's row sums go in `cpart` (segment base + column tile * R; index + row)
 };
-struct SmxAfSeg { int tensor, b; };
+// cp_off / n_rt: the segment's [n_rt][C] block of column partials; rp_off / n_ct: its [n_ct][R] block of row partials
+struct SmxAfSeg { int tensor, b, cp_off, n_rt, rp_off, n_ct; };
 struct SmxAfParams {
     float* p;
     const float* g;
@@ -42,6 +53,8 @@ struct SmxAfParams {
     float* cacc;
     float* rmean;                 // [nsegs]
     float* usq;                   // [ntensors] sum upd^2
+    float* usq_part;              // [ntiles] per-tile sum upd^2
+    float* cpart;                 // column partials of the row tiles ([n_rt][C] per segment with more than one row tile)
     const float* beta2t;          // [ntensors] (tensors without a gradient this step: < 0 -> skipped, as HF does)
     const float* gnorm_sq;        // device scalar for global-norm clipping or null
     long long racc_n, cacc_n;
@@ -82,30 +95,34 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
             s += u * u;
         }
         s = block_sum(s, &cpart[0][0]);
-        if (threadIdx.x == 0) atomicAdd(o.usq + tl.tensor, s);
+        if (threadIdx.x == 0) o.usq_part[blockIdx.x] = s;
         return;
     }
     float* racc = o.racc + T.row_off + (long long)tl.b * T.R;
     float* cacc = o.cacc + T.col_off + (long long)tl.b * T.C + tl.c0;
     if (T.C < 64) {
-        // narrow matrices (conv kernels [Co, Ci, k]: C = k): one thread per row, column sums through LDS atomics; such
-        // a tile always covers its whole (R x C) matrix
-        float* lc = &cpart[0][0];
-        if (threadIdx.x < T.C) lc[threadIdx.x] = 0.f;
-        __syncthreads();
+        // narrow matrices (conv kernels [Co, Ci, k]: C = k): one thread per row; such a tile always covers its whole (R x C)
+        // matrix.  Column sums: every thread's own rows first, then one fixed-order block reduction per column (LDS atomics
+        // added in arrival order here until round 3)
         for (int r = tl.r0 + threadIdx.x; r < tl.r0 + tl.nr; r += 256) {
             const float* gr = g + (long long)r * T.C;
             float rs = 0.f;
             for (int c = 0; c < T.C; ++c) {
                 const float gi = gr[c] * gs;
-                const float u = gi * gi + o.eps1;
-                rs += u;
-                atomicAdd(lc + c, u);
+                rs += gi * gi + o.eps1;
             }
             racc[r] = rs;
         }
-        __syncthreads();
-        if (threadIdx.x < T.C) cacc[threadIdx.x] = lc[threadIdx.x];
+        for (int c = 0; c < T.C; ++c) {
+            float a = 0.f;
+            for (int r = tl.r0 + threadIdx.x; r < tl.r0 + tl.nr; r += 256) {
+                const float gi = g[(long long)r * T.C + c] * gs;
+                a += gi * gi + o.eps1;
+            }
+            __syncthreads();
+            a = block_sum(a, &cpart[0][0]);
+            if (threadIdx.x == 0) cacc[c] = a;
+        }
         return;
     }
     // wide: wave w takes rows r0 + w, + 4 ...; a lane takes 4 consecutive columns c0 + 4 (lane + 64 j) (16-B loads when
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
             rs = wave_sum(rs);
             if (lane == 0) {
                 if (tl.full_rows) racc[r + 4 * k] = rs;
-                else atomicAdd(racc + r + 4 * k, rs);
+                else o.cpart[tl.rp_off + r + 4 * k] = rs;
             }
         }
     }
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
     for (int c = threadIdx.x; c < tl.nc; c += 256) {
         const float sum = (cpart[0][c] + cpart[1][c]) + (cpart[2][c] + cpart[3][c]);
         if (tl.full_cols) cacc[c] = sum;
-        else atomicAdd(cacc + c, sum);
+        else o.cpart[tl.cp_off + c] = sum;
     }
 }
 
@@ -190,12 +207,19 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
     const float* cacc = o.cacc + T.col_off + (long long)sg.b * T.C;
     const float ic = 1.0f / (float)T.C, ir = 1.0f / (float)T.R;
     float s = 0.f;
+    const float* rp = o.cpart + sg.rp_off;
+    auto rsum = [&](int r) -> float {            // row sum of u: one column tile, or the column tiles' partials in tile order
+        if (sg.n_ct <= 1) return racc[r];
+        float a = 0.f;
+        for (int t = 0; t < sg.n_ct; ++t) a += rp[(long long)t * T.R + r];
+        return a;
+    };
     // (the embedding's 50 k rows are one segment, 196 trips per thread: eight trips' loads in flight instead of one)
     int r = threadIdx.x;
     for (; r + 7 * 256 < T.R; r += 8 * 256) {
         float a[8], b[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { a[i] = row[r + i * 256]; b[i] = racc[r + i * 256]; }
+        for (int i = 0; i < 8; ++i) { a[i] = row[r + i * 256]; b[i] = rsum(r + i * 256); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float v = b2 * a[i] + (1.f - b2) * (b[i] * ic);
@@ -204,11 +228,29 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
         }
     }
     for (; r < T.R; r += 256) {
-        const float v = b2 * row[r] + (1.f - b2) * (racc[r] * ic);
+        const float v = b2 * row[r] + (1.f - b2) * (rsum(r) * ic);
         row[r] = v;
         s += v;
     }
-    for (int c = threadIdx.x; c < T.C; c += 256) col[c] = b2 * col[c] + (1.f - b2) * (cacc[c] * ir);
+    if (sg.n_rt <= 1) {
+        for (int c = threadIdx.x; c < T.C; c += 256) col[c] = b2 * col[c] + (1.f - b2) * (cacc[c] * ir);
+    } else {
+        // column sums = the row tiles' partials added in tile order (eight loads in flight per column)
+        const float* cp = o.cpart + sg.cp_off;
+        for (int c = threadIdx.x; c < T.C; c += 256) {
+            float a = 0.f;
+            int t = 0;
+            for (; t + 8 <= sg.n_rt; t += 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = cp[(long long)(t + i) * T.C + c];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a += v[i];
+            }
+            for (; t < sg.n_rt; ++t) a += cp[(long long)t * T.C + c];
+            col[c] = b2 * col[c] + (1.f - b2) * (a * ir);
+        }
+    }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) o.rmean[T.rm_off + sg.b] = s * ir;
 }
@@ -308,8 +350,20 @@ __global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o) {
     }
     if (!APPLY) {
         s = block_sum(s, sh);
-        if (threadIdx.x == 0) atomicAdd(o.usq + tl.tensor, s);
+        if (threadIdx.x == 0) o.usq_part[blockIdx.x] = s;
     }
+}
+
+// ---- usq: a tensor's sum upd^2 = its tiles' partials in a fixed order (one wave per tensor: lane l adds tiles l, l + 64, ...
+// in order, then the fixed wave tree) -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void af_usq_kernel(SmxAfParams o) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= o.ntensors || o.beta2t[t] < 0.f) return;
+    const SmxAfTensor T = o.tensors[t];
+    float a = 0.f;
+    for (int i = lane; i < T.ntile; i += 64) a += o.usq_part[T.tile0 + i];
+    a = wave_sum(a);
+    if (lane == 0) o.usq[t] = a;
 }
 
 extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
@@ -317,13 +371,11 @@ extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
     SmxAfParams o = *op;
     if (o.ntiles <= 0 || o.ntensors <= 0) return SMX_OK;
     if (!o.p || !o.g || !o.tensors || !o.tiles || !o.segs || !o.row || !o.col || !o.racc || !o.cacc || !o.rmean || !o.usq ||
-        !o.beta2t) return SMX_EINVAL;
-    (void)hipMemsetAsync(o.racc, 0, sizeof(float) * o.racc_n, stream);
-    (void)hipMemsetAsync(o.cacc, 0, sizeof(float) * o.cacc_n, stream);
-    (void)hipMemsetAsync(o.usq, 0, sizeof(float) * o.ntensors, stream);
+        !o.usq_part || !o.cpart || !o.beta2t) return SMX_EINVAL;
     hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
     if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
     hipLaunchKernelGGL(af_update_kernel<false>, dim3(o.ntiles), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_usq_kernel, dim3((o.ntensors + 3) / 4), dim3(256), 0, stream, o);
     hipLaunchKernelGGL(af_update_kernel<true>, dim3(o.ntiles), dim3(256), 0, stream, o);
     SMX_CHECK_LAUNCH();
 }
@@ -331,3 +383,4 @@ extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
 extern "C" int smx_sizeof_SmxAfParams(void) { return (int)sizeof(SmxAfParams); }
 extern "C" int smx_sizeof_SmxAfTensor(void) { return (int)sizeof(SmxAfTensor); }
 extern "C" int smx_sizeof_SmxAfTile(void) { return (int)sizeof(SmxAfTile); }
+extern "C" int smx_sizeof_SmxAfSeg(void) { return (int)sizeof(SmxAfSeg); }

@@ -5,7 +5,14 @@
 // max_grad_norm and steps the optimizer after the data-parallel gradient all-reduce.
 #include "smx_common.h"
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+// Sum of squares in a FIXED order (round 3): data-parallel replicas derive the clip coefficient from it and must get the same
+// bits from the same all-reduced gradient; the block sums used to meet in one fp32 atomic, in arrival order.  Each block now
+// stores its sum and a second one-block launch adds the stored sums in block order (a "last block adds" form in one launch
+// measured 220 instead of 156 us: its per-block device-scope fence writes the L2 back 2 048 times).
+#define SUMSQ_MAX_BLOCKS 2048
+static __device__ float smx_sumsq_part[SUMSQ_MAX_BLOCKS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n) {
     __shared__ float sh[16];
     float s = 0.f;
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -17,17 +24,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (i < n && i + 4 > n)
         for (long long j = i; j < n; ++j) s += g[j] * g[j];
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) smx_sumsq_part[blockIdx.x] = s;
 }
-// out (one float, zeroed here) = sum g^2
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(int nblocks, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float a = 0.f;                                         // thread t: blocks t, t + 256, ... in order; then the fixed block tree
+    for (int b = threadIdx.x; b < nblocks; b += 256) a += smx_sumsq_part[b];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) *out = a;
+}
+// out (one float) = sum g^2.  One call in flight per device (the partials are a per-device static).
 extern "C" int smx_sumsq(const float* g, long long n, float* out, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale errors left by other runtime users
-    hipMemsetAsync(out, 0, sizeof(float), stream);
-    if (n <= 0) return SMX_OK;
+    if (n <= 0) { hipMemsetAsync(out, 0, sizeof(float), stream); return SMX_OK; }
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > SUMSQ_MAX_BLOCKS) blocks = SUMSQ_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, g, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, stream, g, n);
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, stream, (int)blocks, out);
     SMX_CHECK_LAUNCH();
 }
 

@@ -736,41 +736,56 @@ class AdafactorPlan:
     """Host-built work lists + device state for smx_adafactor_step over a set of tensors living in one flat buffer.
     tensors: [(element offset, shape)] in the flat p / g buffers.  (TF:optimization.py Adafactor: factored second
     moments for >= 2-D tensors over their last two dims, unfactored for 1-D.)"""
-    ROWS_MIN, TILE_ELEMS, MAXC, VEC_TILE = 64, 8192, 2048, 8192
+    ROWS_MIN, TILE_ELEMS, MAXC, VEC_TILE, MAX_RT = 64, 8192, 2048, 8192, 128
 
     def __init__(self, tensors, device):
         import numpy as np
         self.n = len(tensors)
         tt = np.zeros(self.n, dtype=np.dtype([("off", "<i8"), ("nb", "<i4"), ("R", "<i4"), ("C", "<i4"), ("row_off", "<i4"),
-                                               ("col_off", "<i4"), ("rm_off", "<i4"), ("factored", "<i4"), ("_pad", "<i4")]))
+                                               ("col_off", "<i4"), ("rm_off", "<i4"), ("factored", "<i4"), ("tile0", "<i4"),
+                                               ("ntile", "<i4"), ("_pad", "<i4")]))
+        assert tt.dtype.itemsize == C.sizeof(L.AfTensor)
+        # tiles: (tensor, b, r0, nr, c0, nc, full_rows, full_cols, cp_off, rp_off); segs: (tensor, b, cp_off, n_rt, rp_off, n_ct).
+        # Every reduction of the step has a fixed order (csrc/adafactor.hip): a row tile owns row `rt` of its segment's [n_rt][C]
+        # block of column partials (cp_off), a column tile row `ct` of its [n_ct][R] block of row sums (rp_off), the fold adds them
+        # in tile order; a tensor's tiles are contiguous (tile0, ntile).
         tiles, segs = [], []
-        row_n = col_n = rm_n = 0
+        row_n = col_n = rm_n = cp_n = 0
         for t, (off, shape) in enumerate(tensors):
             numel = 1
             for d in shape:
                 numel *= d
+            tile0 = len(tiles)
             if len(shape) >= 2:
                 R, Cn = shape[-2], shape[-1]
                 nb = numel // (R * Cn)
-                tt[t] = (off, nb, R, Cn, row_n, col_n, rm_n, 1, 0)
                 if Cn < 64:
                     tr = R                                   # narrow (conv kernels): the kernel's thread-per-row path
-                else:                                        # tall matrices: taller tiles, fewer column atomics per address
-                    tr = min(R, max(self.ROWS_MIN, self.TILE_ELEMS // Cn, (R + 511) // 512))
+                else:                                        # tall matrices: taller tiles, at most MAX_RT partial rows per column to fold
+                    tr = min(R, max(self.ROWS_MIN, self.TILE_ELEMS // Cn, (R + self.MAX_RT - 1) // self.MAX_RT))
+                n_rt = (R + tr - 1) // tr
+                n_ct = (Cn + self.MAXC - 1) // self.MAXC
                 for b in range(nb):
-                    segs.append((t, b))
-                    for r0 in range(0, R, tr):
-                        for c0 in range(0, Cn, self.MAXC):
-                            tiles.append((t, b, r0, min(tr, R - r0), c0, min(self.MAXC, Cn - c0), int(Cn <= self.MAXC),
-                                          int(tr >= R)))
+                    seg_cp = seg_rp = 0
+                    if n_rt > 1:
+                        seg_cp, cp_n = cp_n, cp_n + n_rt * Cn
+                    if n_ct > 1:
+                        seg_rp, cp_n = cp_n, cp_n + n_ct * R
+                    segs.append((t, b, seg_cp, n_rt, seg_rp, n_ct))
+                    for rt, r0 in enumerate(range(0, R, tr)):
+                        for ct, c0 in enumerate(range(0, Cn, self.MAXC)):
+                            tiles.append((t, b, r0, min(tr, R - r0), c0, min(self.MAXC, Cn - c0), int(n_ct == 1), int(n_rt == 1),
+                                          seg_cp + rt * Cn + c0 if n_rt > 1 else 0, seg_rp + ct * R if n_ct > 1 else 0))
+                tt[t] = (off, nb, R, Cn, row_n, col_n, rm_n, 1, tile0, len(tiles) - tile0, 0)
                 row_n += nb * R
                 col_n += nb * Cn
                 rm_n += nb
             else:
-                tt[t] = (off, 1, 1, numel, 0, col_n, 0, 0, 0)
                 for c0 in range(0, numel, self.VEC_TILE):
-                    tiles.append((t, 0, 0, 1, c0, min(self.VEC_TILE, numel - c0), 1, 1))
+                    tiles.append((t, 0, 0, 1, c0, min(self.VEC_TILE, numel - c0), 1, 1, 0, 0))
+                tt[t] = (off, 1, 1, numel, 0, col_n, 0, 0, tile0, len(tiles) - tile0, 0)
                 col_n += numel
+        assert cp_n < 2 ** 31
         self._numel = []
         for off, shape in tensors:
             n = 1
@@ -781,8 +796,10 @@ class AdafactorPlan:
         self.row_n, self.col_n = max(row_n, 1), max(col_n, 1)
         dev = device
         self.tensors = torch.from_numpy(tt.view(np.uint8).copy()).to(dev)
-        self.tiles = torch.tensor(tiles if tiles else [[0] * 8], dtype=torch.int32, device=dev)
-        self.segs = torch.tensor(segs if segs else [[0, 0]], dtype=torch.int32, device=dev)
+        self.tiles = torch.tensor(tiles if tiles else [[0] * 10], dtype=torch.int32, device=dev)
+        self.segs = torch.tensor(segs if segs else [[0] * 6], dtype=torch.int32, device=dev)
+        self.usq_part = torch.zeros(max(len(tiles), 1), dtype=torch.float32, device=dev)
+        self.cpart = torch.empty(max(cp_n, 1), dtype=torch.float32, device=dev)
         self.row = torch.zeros(self.row_n, dtype=torch.float32, device=dev)
         self.col = torch.zeros(self.col_n, dtype=torch.float32, device=dev)
         self.racc = torch.empty(self.row_n, dtype=torch.float32, device=dev)
@@ -820,6 +837,7 @@ class AdafactorPlan:
         o.tensors, o.tiles, o.segs = _ptr(self.tensors), _ptr(self.tiles), _ptr(self.segs)
         o.row, o.col, o.racc, o.cacc, o.rmean, o.usq = _ptr(self.row), _ptr(self.col), _ptr(self.racc), _ptr(self.cacc), \
             _ptr(self.rmean), _ptr(self.usq)
+        o.usq_part, o.cpart = _ptr(self.usq_part), _ptr(self.cpart)
         o.beta2t, o.gnorm_sq = _ptr(self.beta2t), _ptr(gnorm_sq)
         o.racc_n, o.cacc_n, o.ntensors, o.ntiles, o.nsegs = self.row_n, self.col_n, self.n, self.ntiles, self.nsegs
         o.lr, o.eps1, o.clip_threshold, o.grad_scale, o.max_grad_norm = lr, eps1, clip_threshold, grad_scale, max_grad_norm

@@ -38,7 +38,7 @@ def test_struct_layouts_match_ctypes(lib):
     for name, st in (("SmxGemmParams", L.GemmParams), ("SmxNormParams", L.NormParams), ("SmxNormBwdParams", L.NormBwdParams),
                      ("SmxAttnParams", L.AttnParams), ("SmxConv0Params", L.Conv0Params), ("SmxCEParams", L.CEParams),
                      ("SmxOptParams", L.OptParams), ("SmxWsumParams", L.WsumParams), ("SmxAfParams", L.AfParams),
-                     ("SmxAfTensor", L.AfTensor), ("SmxAfTile", L.AfTile), ("SmxFoldTable", L.FoldTable)):
+                     ("SmxAfTensor", L.AfTensor), ("SmxAfTile", L.AfTile), ("SmxAfSeg", L.AfSeg), ("SmxFoldTable", L.FoldTable)):
         assert getattr(lib, "smx_sizeof_" + name)() == C.sizeof(st), name
     assert lib.smx_fold_max() == L.FOLD_MAX
 
@@ -47,9 +47,9 @@ def test_header_is_plain_c_and_agrees_with_library(lib, tmp_path):
     """The header must be consumable from C (the drop-in boundary is a C ABI) and give the same sizes."""
     prog = tmp_path / "sz.c"
     prog.write_text('#define __HIP_PLATFORM_AMD__ 1\n#include <stdio.h>\n#include "speechmix_hip.h"\n'
-                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(SmxGemmParams), sizeof(SmxNormParams),'
+                    'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(SmxGemmParams), sizeof(SmxNormParams),'
                     ' sizeof(SmxNormBwdParams), sizeof(SmxAttnParams), sizeof(SmxConv0Params), sizeof(SmxCEParams),'
-                    ' sizeof(SmxOptParams), sizeof(SmxWsumParams), sizeof(SmxAfParams), sizeof(SmxAfTensor), sizeof(SmxAfTile));'
+                    ' sizeof(SmxOptParams), sizeof(SmxWsumParams), sizeof(SmxAfParams), sizeof(SmxAfTensor), sizeof(SmxAfTile), sizeof(SmxAfSeg));'
                     ' return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", str(prog), "-o", str(exe)],
@@ -57,7 +57,7 @@ def test_header_is_plain_c_and_agrees_with_library(lib, tmp_path):
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     want = [getattr(lib, "smx_sizeof_" + n)() for n in ("SmxGemmParams", "SmxNormParams", "SmxNormBwdParams", "SmxAttnParams",
                                                          "SmxConv0Params", "SmxCEParams", "SmxOptParams", "SmxWsumParams", "SmxAfParams",
-                                                         "SmxAfTensor", "SmxAfTile")]
+                                                         "SmxAfTensor", "SmxAfTile", "SmxAfSeg")]
     assert got == want
 
 

@@ -253,3 +253,27 @@ def test_streamed_lm_head_equals_the_materialised_one(dtype, tol, monkeypatch):
     worst = max(((g0[k] - g1[k]).abs().max().item() / max(g0[k].abs().max().item(), 1e-8), k) for k in g0)
     print(f"[streamed head {dtype}] loss {l0:.6f} vs {l1:.6f}; worst gradient difference {worst[0]:.3e} ({worst[1]})")
     assert worst[0] <= (1e-4 if dtype == "fp32" else 5e-2)
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_over_gloo_through_the_whole_step():
+    """The N > 1 step on the REAL kernels (the gloo tests in test_dist_cpu.py drive the reducer with synthetic gradients): two
+    ranks, both on cuda:0, gloo as the transport (RCCL refuses two ranks on one device) - per-rank LayerDrop / SpecAugment
+    draws, stage buckets reduced on the side stream while backward runs, rank 0's kernel picks broadcast after steps 1 and 3,
+    the CU reserve for the collective, clip + Adafactor on identical reduced gradients.  bench.py's own launch path
+    (`--gpus 2` without a launcher) starts the ranks.  Checked: one JSON line from rank 0, n_gpus 2, weak scaling
+    (global batch 2 x 4), finite loss; and, from a second run with SMX_BENCH_CHECK_SYNC=1, parameters bit-identical on both ranks
+    after the steps."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMX_BENCH_SHARED_GPU="1", SMX_BENCH_CHECK_SYNC="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline", "--no-profile", "--no-eval-leg", "--seed", "3"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 50
+    assert d.get("params_in_sync") is True, d
