@@ -277,3 +277,27 @@ def test_two_ranks_share_one_gpu_over_gloo_through_the_whole_step():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
     assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 50
     assert d.get("params_in_sync") is True, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grad_accum", [1, 2])
+def test_two_rank_gradient_equals_the_single_batch_gradient(grad_accum):
+    """Data-parallel equivalence on the real kernels (tools/gpu_dp_equiv.py, two ranks sharing cuda:0 over gloo): what two
+    ranks x 2 clips x grad_accum micro-batches all-reduce is the gradient of the same clips as one batch (fp32 path, eval mode,
+    real base-model widths), the SGD step from it lands on the same parameters, and both ranks hold the same bits.  Bound:
+    fp32 summation order (batch rows are summed in a different grouping) - 2e-5 of the largest gradient entry."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "gpu_dp_equiv.py"), str(grad_accum)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(d)
+    assert d["in_sync"] and d["moved"] > 0
+    assert d["grad_rel_err"] <= 2e-5, d
+    assert d["param_abs_err"] <= 0.5 * 2e-5 * d["grad_max"] + 1e-7, d
