@@ -280,11 +280,13 @@ def test_two_ranks_share_one_gpu_over_gloo_through_the_whole_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grad_accum", [1, 2])
-def test_two_rank_gradient_equals_the_single_batch_gradient(grad_accum):
+@pytest.mark.parametrize("grad_accum,kind", [(1, "eed"), (2, "eed"), (1, "self")])
+def test_two_rank_gradient_equals_the_single_batch_gradient(grad_accum, kind):
     """Data-parallel equivalence on the real kernels (tools/gpu_dp_equiv.py, two ranks sharing cuda:0 over gloo): what two
     ranks x 2 clips x grad_accum micro-batches all-reduce is the gradient of the same clips as one batch (fp32 path, eval mode,
-    real base-model widths), the SGD step from it lands on the same parameters, and both ranks hold the same bits.  Bound:
+    real base-model widths), the SGD step from it lands on the same parameters, and both ranks hold the same bits.  "self":
+    SpeechMixSelf (wav2vec2-base, half its layers kept, frozen t5-small, text pass: CE + KLD(batchmean) + MSE) - only the trainable
+    ranges are reduced.  Bound:
     fp32 summation order (batch rows are summed in a different grouping) - 2e-5 of the largest gradient entry."""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -293,11 +295,11 @@ def test_two_rank_gradient_equals_the_single_batch_gradient(grad_accum):
         port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "tools", "gpu_dp_equiv.py"), str(grad_accum)],
+                        "--master-port", str(port), os.path.join(root, "tools", "gpu_dp_equiv.py"), str(grad_accum), kind],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     print(d)
-    assert d["in_sync"] and d["moved"] > 0
+    assert d["in_sync"] and d["moved"] > 0 and (d["frozen_tensors"] > 0) == (kind == "self")
     assert d["grad_rel_err"] <= 2e-5, d
     assert d["param_abs_err"] <= 0.5 * 2e-5 * d["grad_max"] + 1e-7, d
