@@ -201,13 +201,14 @@ int smx_optimizer_step(const SmxOptParams* p, hipStream_t stream);
  * loop of TF:optimization.py Adafactor.step.  Work lists are built by the caller (speechmix_amd/ops.py AdafactorPlan). */
 /* Every reduction of the step runs in a fixed order (no order-dependent fp32 atomics): data-parallel replicas that apply it to the
  * same all-reduced gradients keep bit-identical parameters.  tile0 / ntile: a tensor's (contiguous) tiles; cp_off / rp_off: where a
+ * The global gradient norm for clipping (max_grad_norm > 0) is computed by the step itself from its statistics pass (gsq_part -> gn2).
  * tile's column partials / row sums go in `cpart` ([row tiles][C] and [column tiles][R] blocks per (tensor, leading index)). */
 typedef struct SmxAfTensor { long long off; int nb, R, C, row_off, col_off, rm_off, factored, tile0, ntile, _pad; } SmxAfTensor;
 typedef struct SmxAfTile { int tensor, b, r0, nr, c0, nc, full_rows, full_cols, cp_off, rp_off; } SmxAfTile;
 typedef struct SmxAfSeg { int tensor, b, cp_off, n_rt, rp_off, n_ct; } SmxAfSeg;
 typedef struct SmxAfParams {
     float* p; const float* g; void* shadow; const SmxAfTensor* tensors; const SmxAfTile* tiles; const SmxAfSeg* segs;
-    float *row, *col, *racc, *cacc, *rmean, *usq, *usq_part, *cpart; const float* beta2t; const float* gnorm_sq;
+    float *row, *col, *racc, *cacc, *rmean, *usq, *usq_part, *cpart; const float* beta2t; float *gn2, *gsq_part;
     long long racc_n, cacc_n; int ntensors, ntiles, nsegs;
     float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
 } SmxAfParams;

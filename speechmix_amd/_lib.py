@@ -136,7 +136,7 @@ class AfParams(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("shadow", C.c_void_p), ("tensors", C.c_void_p), ("tiles", C.c_void_p),
                 ("segs", C.c_void_p), ("row", C.c_void_p), ("col", C.c_void_p), ("racc", C.c_void_p), ("cacc", C.c_void_p),
                 ("rmean", C.c_void_p), ("usq", C.c_void_p), ("usq_part", C.c_void_p), ("cpart", C.c_void_p), ("beta2t", C.c_void_p),
-                ("gnorm_sq", C.c_void_p),
+                ("gn2", C.c_void_p), ("gsq_part", C.c_void_p),
                 ("racc_n", C.c_longlong), ("cacc_n", C.c_longlong), ("ntensors", C.c_int), ("ntiles", C.c_int),
                 ("nsegs", C.c_int), ("lr", C.c_float), ("eps1", C.c_float), ("clip_threshold", C.c_float),
                 ("grad_scale", C.c_float), ("max_grad_norm", C.c_float)]

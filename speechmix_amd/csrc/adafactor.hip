@@ -7,8 +7,10 @@
 //     upd /= max(1, rms(upd) / clip_threshold) ;  p -= lr upd           beta2t = 1 - step^decay_rate
 // The state is two vectors per matrix instead of AdamW's two full copies (2 MB instead of 1.9 GB at config 2).
 //
-// One step = a memset + five launches over host-built work lists (no per-tensor launches: 458 tensors at config 2):
-//   stats   tiles of >= 64 rows x <= 2048 columns: row sums by wave reductions, column partials in registers
+// One step = six launches over host-built work lists (no per-tensor launches: 458 tensors at config 2):
+//   stats   tiles of >= 64 rows x <= 2048 columns: row sums by wave reductions, column partials in registers; also each tile's
+//           sum of squares - the global gradient norm for clipping comes out of this pass (gnorm: one block adds the tiles'
+//           sums in tile order) instead of a pass of its own over the gradient (smx_sumsq: 147 us at config 2)
 //   fold    one block per (tensor, leading index): the two moving averages, the row mean
 //   rms     tiles again: sum upd^2 per tile     usq   per tensor     apply   tiles again: the update + the bf16 compute copy
 // Gradient traffic 3 x 4 B + parameters 8 B + bf16 copy 2 B = 22 B / parameter (AdamW: 30).
@@ -56,7 +58,8 @@ struct SmxAfParams {
     float* usq_part;              // [ntiles] per-tile sum upd^2
     float* cpart;                 // column partials of the row tiles ([n_rt][C] per segment with more than one row tile)
     const float* beta2t;          // [ntensors] (tensors without a gradient this step: < 0 -> skipped, as HF does)
-    const float* gnorm_sq;        // device scalar for global-norm clipping or null
+    float* gn2;                   // device scalar: sum (grad_scale g)^2 over every active tensor, written by the gnorm launch
+    float* gsq_part;              // [ntiles] per-tile sum (grad_scale g)^2
     long long racc_n, cacc_n;
     int ntensors, ntiles, nsegs;
     float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
@@ -65,37 +68,55 @@ struct SmxAfParams {
 #define AF_MAXC 2048
 #define AF_ROWS 64
 
-__device__ __forceinline__ float af_gscale(const SmxAfParams& o) {
-    float s = o.grad_scale;
-    if (o.max_grad_norm > 0.f && o.gnorm_sq) {
-        const float nrm = sqrtf(*o.gnorm_sq) * o.grad_scale;
-        s *= fminf(1.f, o.max_grad_norm / (nrm + 1e-6f));
-    }
-    return s;
+// gradient scale: 1 / world (grad_scale) x the global-norm clip coefficient (HF Trainer: clip_grad_norm_(max_grad_norm), then
+// optimizer.step).  The second moments are linear in the squared scale, so the stats pass runs BEFORE the norm is known, on
+// grad_scale alone, and the fold applies the coefficient's square.
+__device__ __forceinline__ float af_clip(const SmxAfParams& o) {
+    if (!(o.max_grad_norm > 0.f)) return 1.f;
+    return fminf(1.f, o.max_grad_norm / (sqrtf(*o.gn2) + 1e-6f));
 }
+__device__ __forceinline__ float af_gscale(const SmxAfParams& o) { return o.grad_scale * af_clip(o); }
 
-// ---- stats: u = (gs g)^2 + eps1 summed along rows and columns ------------------------------------------------------
+// ---- stats: u0 = (grad_scale g)^2 summed along rows and columns, and over the tile --------------------------------------
 __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
     __shared__ float cpart[4][AF_MAXC];
+    __shared__ float wsum[4];
     const SmxAfTile tl = o.tiles[blockIdx.x];
     const SmxAfTensor T = o.tensors[tl.tensor];
-    if (o.beta2t[tl.tensor] < 0.f) return;
-    const float gs = af_gscale(o);
+    const float gs = o.grad_scale;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float* g = o.g + T.off + (long long)tl.b * T.R * T.C;
-    if (!T.factored) {               // 1-D: v updated in place, sum upd^2 on the fly
-        const float b2 = o.beta2t[tl.tensor];
-        float* v = o.col + T.col_off;
+    if (o.beta2t[tl.tensor] < 0.f) {
+        // no update for this tensor in this step, but whatever its gradient range holds still counts in the global norm (the
+        // norm is taken over the whole flat gradient; a frozen or layer-dropped tensor's range is zeros)
+        float s = 0.f;
+        if (o.max_grad_norm > 0.f) {
+            const bool v4 = !(T.C & 3) && !(tl.c0 & 3) && !(tl.nc & 3);
+            for (int r = tl.r0 + w; r < tl.r0 + tl.nr; r += 4) {
+                const float* gr = g + (long long)r * T.C + tl.c0;
+                if (v4) {
+                    for (int c = 4 * lane; c < tl.nc; c += 256) {
+                        const float4 q = *reinterpret_cast<const float4*>(gr + c);
+                        s += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+                    }
+                } else {
+                    for (int c = lane; c < tl.nc; c += 64) s += gr[c] * gr[c];
+                }
+            }
+            s *= gs * gs;
+        }
+        s = block_sum(s, &cpart[0][0]);
+        if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = s;
+        return;
+    }
+    if (!T.factored) {               // 1-D: only the tile's sum of squares here (v and sum upd^2: the rms launch, once the norm is known)
         float s = 0.f;
         for (int c = tl.c0 + threadIdx.x; c < tl.c0 + tl.nc; c += 256) {
             const float gi = g[c] * gs;
-            const float vi = b2 * v[c] + (1.f - b2) * (gi * gi + o.eps1);
-            v[c] = vi;
-            const float u = gi * rsqrtf(vi);
-            s += u * u;
+            s += gi * gi;
         }
         s = block_sum(s, &cpart[0][0]);
-        if (threadIdx.x == 0) o.usq_part[blockIdx.x] = s;
+        if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = s;
         return;
     }
     float* racc = o.racc + T.row_off + (long long)tl.b * T.R;
@@ -104,25 +125,30 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
         // narrow matrices (conv kernels [Co, Ci, k]: C = k): one thread per row; such a tile always covers its whole (R x C)
         // matrix.  Column sums: every thread's own rows first, then one fixed-order block reduction per column (LDS atomics
         // added in arrival order here until round 3)
+        float tot = 0.f;
         for (int r = tl.r0 + threadIdx.x; r < tl.r0 + tl.nr; r += 256) {
             const float* gr = g + (long long)r * T.C;
             float rs = 0.f;
             for (int c = 0; c < T.C; ++c) {
                 const float gi = gr[c] * gs;
-                rs += gi * gi + o.eps1;
+                rs += gi * gi;
             }
             racc[r] = rs;
+            tot += rs;
         }
         for (int c = 0; c < T.C; ++c) {
             float a = 0.f;
             for (int r = tl.r0 + threadIdx.x; r < tl.r0 + tl.nr; r += 256) {
                 const float gi = g[(long long)r * T.C + c] * gs;
-                a += gi * gi + o.eps1;
+                a += gi * gi;
             }
             __syncthreads();
             a = block_sum(a, &cpart[0][0]);
             if (threadIdx.x == 0) cacc[c] = a;
         }
+        __syncthreads();
+        tot = block_sum(tot, &cpart[0][0]);
+        if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = tot;
         return;
     }
     // wide: wave w takes rows r0 + w, + 4 ...; a lane takes 4 consecutive columns c0 + 4 (lane + 64 j) (16-B loads when
@@ -134,6 +160,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) cs[j][e] = 0.f;
+    float wtot = 0.f;                       // this wave's rows, in row order
     // two rows per trip with all their loads issued first: a wave walks 16+ rows of a tile, and one row's 16-B loads are
     // too few bytes in flight to stream at HBM speed
     for (int r = tl.r0 + w; r < tl.r0 + tl.nr; r += 8) {
@@ -169,13 +196,14 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float gi = x[k][j][e] * gs;
-                        const float u = (v4 || c + e < tl.nc) ? gi * gi + o.eps1 : 0.f;
+                        const float u = gi * gi;             // (columns beyond the tile were loaded as zeros)
                         rs += u;
                         cs[j][e] += u;
                     }
                 }
             }
             rs = wave_sum(rs);
+            wtot += rs;
             if (lane == 0) {
                 if (tl.full_rows) racc[r + 4 * k] = rs;
                 else o.cpart[tl.rp_off + r + 4 * k] = rs;
@@ -192,6 +220,18 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
         if (tl.full_cols) cacc[c] = sum;
         else o.cpart[tl.cp_off + c] = sum;
     }
+    if (lane == 0) wsum[w] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// ---- gnorm: sum (grad_scale g)^2 over all tiles, in tile order -----------------------------------
+__global__ __launch_bounds__(1024) void af_gnorm_kernel(SmxAfParams o) {
+    __shared__ float sh[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < o.ntiles; i += 1024) a += o.gsq_part[i];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) *o.gn2 = a;
 }
 
 // ---- fold: moving averages of one (tensor, leading index), and the mean of its row state ---------------------------
@@ -206,13 +246,17 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
     float* col = o.col + T.col_off + (long long)sg.b * T.C;
     const float* cacc = o.cacc + T.col_off + (long long)sg.b * T.C;
     const float ic = 1.0f / (float)T.C, ir = 1.0f / (float)T.R;
+    // u = (clip grad_scale g)^2 + eps1: the stats pass summed (grad_scale g)^2; the clip coefficient's square and the eps1 terms
+    // (one per summed element) come in here
+    const float c2 = af_clip(o) * af_clip(o), er = (float)T.C * o.eps1, ec = (float)T.R * o.eps1;
     float s = 0.f;
     const float* rp = o.cpart + sg.rp_off;
     auto rsum = [&](int r) -> float {            // row sum of u: one column tile, or the column tiles' partials in tile order
-        if (sg.n_ct <= 1) return racc[r];
         float a = 0.f;
-        for (int t = 0; t < sg.n_ct; ++t) a += rp[(long long)t * T.R + r];
-        return a;
+        if (sg.n_ct <= 1) a = racc[r];
+        else
+            for (int t = 0; t < sg.n_ct; ++t) a += rp[(long long)t * T.R + r];
+        return fmaf(a, c2, er);
     };
     // (the embedding's 50 k rows are one segment, 196 trips per thread: eight trips' loads in flight instead of one)
     int r = threadIdx.x;
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
         s += v;
     }
     if (sg.n_rt <= 1) {
-        for (int c = threadIdx.x; c < T.C; c += 256) col[c] = b2 * col[c] + (1.f - b2) * (cacc[c] * ir);
+        for (int c = threadIdx.x; c < T.C; c += 256) col[c] = b2 * col[c] + (1.f - b2) * (fmaf(cacc[c], c2, ec) * ir);
     } else {
         // column sums = the row tiles' partials added in tile order (eight loads in flight per column)
         const float* cp = o.cpart + sg.cp_off;
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
                 for (int i = 0; i < 8; ++i) a += v[i];
             }
             for (; t < sg.n_rt; ++t) a += cp[(long long)t * T.C + c];
-            col[c] = b2 * col[c] + (1.f - b2) * (a * ir);
+            col[c] = b2 * col[c] + (1.f - b2) * (fmaf(a, c2, ec) * ir);
         }
     }
     s = block_sum(s, sh);
@@ -273,7 +317,21 @@ __global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o) {
     }
     bf16_t* shd = reinterpret_cast<bf16_t*>(o.shadow);
     if (!T.factored) {
-        if (!APPLY) return;                  // sum upd^2 was taken by the stats pass
+        if (!APPLY) {                        // 1-D: v updated in place, sum upd^2 on the fly
+            const float b2 = o.beta2t[tl.tensor];
+            float* v = o.col + T.col_off;
+            float s1 = 0.f;
+            for (int c = tl.c0 + threadIdx.x; c < tl.c0 + tl.nc; c += 256) {
+                const float gi = g[c] * gs;
+                const float vi = b2 * v[c] + (1.f - b2) * (gi * gi + o.eps1);
+                v[c] = vi;
+                const float u = gi * rsqrtf(vi);
+                s1 += u * u;
+            }
+            s1 = block_sum(s1, sh);
+            if (threadIdx.x == 0) o.usq_part[blockIdx.x] = s1;
+            return;
+        }
         const float* v = o.col + T.col_off;
         for (int c = tl.c0 + threadIdx.x; c < tl.c0 + tl.nc; c += 256) {
             const float pi = o.p[base + c] - scale * (g[c] * gs) * rsqrtf(v[c]);
@@ -371,8 +429,9 @@ extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
     SmxAfParams o = *op;
     if (o.ntiles <= 0 || o.ntensors <= 0) return SMX_OK;
     if (!o.p || !o.g || !o.tensors || !o.tiles || !o.segs || !o.row || !o.col || !o.racc || !o.cacc || !o.rmean || !o.usq ||
-        !o.usq_part || !o.cpart || !o.beta2t) return SMX_EINVAL;
+        !o.usq_part || !o.cpart || !o.beta2t || !o.gsq_part || !o.gn2) return SMX_EINVAL;
     hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
+    if (o.max_grad_norm > 0.f) hipLaunchKernelGGL(af_gnorm_kernel, dim3(1), dim3(1024), 0, stream, o);
     if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
     hipLaunchKernelGGL(af_update_kernel<false>, dim3(o.ntiles), dim3(256), 0, stream, o);
     hipLaunchKernelGGL(af_usq_kernel, dim3((o.ntensors + 3) / 4), dim3(256), 0, stream, o);

@@ -799,6 +799,8 @@ class AdafactorPlan:
         self.tiles = torch.tensor(tiles if tiles else [[0] * 10], dtype=torch.int32, device=dev)
         self.segs = torch.tensor(segs if segs else [[0] * 6], dtype=torch.int32, device=dev)
         self.usq_part = torch.zeros(max(len(tiles), 1), dtype=torch.float32, device=dev)
+        self.gsq_part = torch.zeros(max(len(tiles), 1), dtype=torch.float32, device=dev)
+        self.gn2 = torch.zeros(1, dtype=torch.float32, device=dev)          # sum (grad_scale g)^2 of the last step (clipping on)
         self.cpart = torch.empty(max(cp_n, 1), dtype=torch.float32, device=dev)
         self.row = torch.zeros(self.row_n, dtype=torch.float32, device=dev)
         self.col = torch.zeros(self.col_n, dtype=torch.float32, device=dev)
@@ -818,7 +820,9 @@ class AdafactorPlan:
 
     def step(self, p, g, shadow, gnorm_sq, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
              max_grad_norm=0.0):
-        """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched)."""
+        """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched).
+        max_grad_norm > 0: global-norm clipping (HF Trainer's clip_grad_norm_ before optimizer.step); the norm comes out of the
+        step's own statistics pass over the gradient (`gnorm_sq` is accepted for the older calling convention and ignored)."""
         np = self._np
         act = np.ones(self.n, dtype=bool) if active is None else np.asarray(active, dtype=bool)
         self.steps[act] += 1
@@ -838,7 +842,7 @@ class AdafactorPlan:
         o.row, o.col, o.racc, o.cacc, o.rmean, o.usq = _ptr(self.row), _ptr(self.col), _ptr(self.racc), _ptr(self.cacc), \
             _ptr(self.rmean), _ptr(self.usq)
         o.usq_part, o.cpart = _ptr(self.usq_part), _ptr(self.cpart)
-        o.beta2t, o.gnorm_sq = _ptr(self.beta2t), _ptr(gnorm_sq)
+        o.beta2t, o.gn2, o.gsq_part = _ptr(self.beta2t), _ptr(self.gn2), _ptr(self.gsq_part)
         o.racc_n, o.cacc_n, o.ntensors, o.ntiles, o.nsegs = self.row_n, self.col_n, self.n, self.ntiles, self.nsegs
         o.lr, o.eps1, o.clip_threshold, o.grad_scale, o.max_grad_norm = lr, eps1, clip_threshold, grad_scale, max_grad_norm
         nact = float(sum(t[1] for t, a in zip(self._numel, act) if a)) if hasattr(self, "_numel") else 0.0

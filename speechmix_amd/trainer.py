@@ -151,7 +151,7 @@ class StepRunner:
         lr = self.current_lr()
         inv_world = 1.0 / self.world
         clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
-        if clip > 0:
+        if clip > 0 and self.af is None:          # (Adafactor takes the norm from its own statistics pass)
             ops.sumsq(st.grad, st.total, self.gnorm_sq)
         sh = None if st.shadow is st.master else st.shadow
         # torch / HF optimizers skip parameters whose .grad is None: a LayerDrop-dropped layer's (on one rank; across ranks the

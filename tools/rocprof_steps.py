@@ -1,5 +1,5 @@
 """Per-step kernel table from a rocprofv3 --kernel-trace CSV of bench.py: drops the warm-up steps (steps are delimited
-by the optimizer's sumsq kernel) and aggregates by (kernel, grid).   python tools/rocprof_steps.py trace.csv WARMUP"""
+by the optimizer: Adafactor's af_gnorm kernel, else the sumsq kernel of the AdamW / SGD path) and aggregates by (kernel, grid).   python tools/rocprof_steps.py trace.csv WARMUP"""
 import collections, csv, sys
 path, warm = sys.argv[1], int(sys.argv[2])
 rows = []
@@ -8,7 +8,7 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Grid_Size_Z"]),
                      int(r["Workgroup_Size_X"])))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if "sumsq" in r[2]]
+idx = [i for i, r in enumerate(rows) if "af_gnorm" in r[2]] or [i for i, r in enumerate(rows) if "sumsq_kernel" in r[2]]
 sel = rows[idx[warm - 1]:idx[-1]] if warm > 0 else rows[:idx[-1]]
 steps = len(idx) - warm
 agg = collections.defaultdict(lambda: [0, 0.0])
