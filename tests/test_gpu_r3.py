@@ -303,3 +303,40 @@ def test_two_rank_gradient_equals_the_single_batch_gradient(grad_accum, kind):
     assert d["in_sync"] and d["moved"] > 0 and (d["frozen_tensors"] > 0) == (kind == "self")
     assert d["grad_rel_err"] <= 2e-5, d
     assert d["param_abs_err"] <= 0.5 * 2e-5 * d["grad_max"] + 1e-7, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,D", [(20000, 768), (7001, 512), (6150, 1024), (3, 64), (4097, 32)])
+@pytest.mark.parametrize("rms,res", [(False, True), (True, False)])
+def test_persistent_norm_kernels_match_torch_at_any_row_count(M, D, rms, res):
+    """The LayerNorm / RMSNorm kernels walk the rows with a fixed number of resident blocks (6 per CU forward, 3 per CU backward):
+    row counts above and below those grids, ragged tails, narrow and wide rows - forward, dx (+ residual gradient) and the
+    gamma / beta gradients against fp32 torch autograd on the same bf16-rounded inputs."""
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g).to(dev).bfloat16(); dy = torch.randn(M, D, generator=g).to(dev).bfloat16()
+    dres = torch.randn(M, D, generator=g).to(dev).bfloat16() if res else None
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev); beta = None if rms else (0.1 * torch.randn(D, generator=g)).to(dev)
+    y = torch.empty_like(x); dx = torch.empty_like(x)
+    mean = None if rms else torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+    dg = torch.zeros(D, device=dev); db = None if rms else torch.zeros(D, device=dev)
+    ops.norm_fwd(x, y, gamma, beta, mean, rstd, M, D, ops.BF16, rms=rms)
+    folds = ops.FoldQueue()
+    ops.norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dg, db, M, D, ops.BF16, rms=rms, dres=dres, folds=folds)
+    folds.flush()
+    torch.cuda.synchronize()
+    xr = x.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True) if beta is not None else None
+    if rms:
+        yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * gr
+    else:
+        yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    yr.backward(dy.float())
+    want_dx = xr.grad + (dres.float() if res else 0)
+    assert (y.float() - yr.detach()).abs().max().item() <= 2 ** -7 * yr.detach().abs().max().item()
+    assert (dx.float() - want_dx).abs().max().item() <= 2 ** -7 * want_dx.abs().max().item()
+    assert (dg - gr.grad).abs().max().item() <= 2e-5 * gr.grad.abs().max().item() + 1e-4
+    if br is not None:
+        assert (db - br.grad).abs().max().item() <= 2e-5 * br.grad.abs().max().item() + 1e-4
