@@ -61,9 +61,6 @@ __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[NB][4], FRFrags<NB>& f, c
         f.a[fr_slot<1 - PAR, NB>(NB - 2)] = fr_afrag<A_RC, NB>(nstage, NB - 2, 1 - PAR, wr, lane);
         f.a[fr_slot<1 - PAR, NB>(NB - 1)] = fr_afrag<A_RC, NB>(nstage, NB - 1, 1 - PAR, wr, lane);
     }
-#ifdef FR_DBG_WAIT
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
@@ -74,9 +71,6 @@ __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[NB][4], FRFrags<NB>& f, c
         if constexpr (CH == 1 && READ) {
             if (g < NB - 2) f.a[g] = fr_afrag<A_RC, NB>(nstage, g, 1 - PAR, wr, lane);
         }
-#ifdef FR_DBG_WAIT
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ISSUE != 0) {
             if (g == 1) { if (ISSUE == 1) is.template issue<0>(tid); else is.template issue<2>(tid); __builtin_amdgcn_sched_barrier(0); }
@@ -127,9 +121,6 @@ __device__ __forceinline__ void fr_kernel_body() {
         all &= is.template issue<3>(tid);
         all &= is.template issue<0>(tid);
         all &= is.template issue<1>(tid);
-#ifdef FR_DBG_V0
-        all = false;
-#endif
         if (all) PP_WAITV(4);
         else PP_WAITV(0);
     }
@@ -168,36 +159,19 @@ __device__ __forceinline__ void fr_kernel_body() {
         }
         // the item's K tile 0 is resident: prologue barrier, or the SYNC inside the previous item's last half step
         fr_read_first<A_RC, B_RC, NB>(f, smem + (seq & 1) * PP_STAGE, wr, wc, lane);
-#ifdef FR_DBG_SYNCALL
-        FR_SYNC();
-#endif
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < it.nk; ++t) {
             const char* cur = smem + (seq & 1) * PP_STAGE;
             const char* oth = smem + ((seq & 1) ^ 1) * PP_STAGE;
             // H0 (k 0..31 of tile t): pass 0 issues the last two units of stream tile seq+1, pass 1 reads k 32..63 of tile t
             fr_pass<A_RC, B_RC, 0, 0, true, 2, NB>(acc, f, cur, cur, is, tid, lane, wr, wc);
-#ifdef FR_DBG_SYNCALL
-            FR_SYNC();
-#endif
             fr_pass<A_RC, B_RC, 0, 1, true, 0, NB>(acc, f, cur, cur, is, tid, lane, wr, wc);
-#ifdef FR_DBG_SYNCALL
-            FR_SYNC();
-#endif
             // H1 (k 32..63): pass 0; SYNC: stream tile seq+1 resident for everyone, every read of tile t done -> its stage is free;
             // pass 1 reads k 0..31 of the item's next tile and issues the first two units of stream tile seq+2 into this stage
             fr_pass<A_RC, B_RC, 1, 0, true, 0, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
             FR_SYNC();
             // (in the item's last tile these reads fetch the next item's first fragments and are dropped: one copy of the pass)
-#ifdef FR_DBG_NOGARB
-            if (t + 1 < it.nk) fr_pass<A_RC, B_RC, 1, 1, true, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
-            else fr_pass<A_RC, B_RC, 1, 1, false, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
-#else
             fr_pass<A_RC, B_RC, 1, 1, true, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
-#endif
-#ifdef FR_DBG_SYNCALL
-            FR_SYNC();
-#endif
             ++seq;
         }
         if (fast_epi) {
