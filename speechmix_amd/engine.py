@@ -1415,26 +1415,47 @@ class Engine:
 
         def cat_b(pair_a, pair_b):
             return self.st.cat([pair_a[1], pair_b[1]], "p32") if pair_a[1] else None
-        # cross-attention K/V of every layer, once
-        xkv = []
-        for nm in names:
-            kn, vn = nm["xattn"]["k"], nm["xattn"]["v"]
-            xkv.append(self.lin(enc, self.st.cat([kn[0], vn[0]]), cat_b(kn, vn), B * S, 2 * d, d))
-        cache = [self.zeros(B, Lmax, 2 * d) for _ in names]            # self-attention K | V per position
         V = lc.vocab_size
         Vp = (V + 7) // 8 * 8
         head = lp + "lm_head.weight" if self.has(lp + "lm_head.weight") else emb_name
         flb = self.st.module.get_buffer(lp + "final_logits_bias").view(-1) if not t5 else None
         head_alpha = d ** -0.5 if (t5 and lc.tie_word_embeddings) else 1.0
-        pbias = self._t5_bias("decoder", Lmax, Lmax)[0] if t5 else None          # [H, Lmax, Lmax]: row t = step t's bias
-        logits = self.new(B, Vp, dt=torch.float32)
-        tok = torch.full((B,), start_id, dtype=torch.int64, device=self.dev)
-        nxt = torch.empty(B, dtype=torch.int64, device=self.dev)
-        done = torch.zeros(B, dtype=torch.bool, device=self.dev)
-        out = torch.full((B, Lmax), pad_id, dtype=torch.int64, device=self.dev)
-        lse = self.new(B * H, dt=torch.float32)
-        steps = 0
-        for t in range(Lmax):
+        # Decoding state.  Plain calls own theirs; graph-replayed calls (below) share one static set per configuration, because
+        # a captured step holds the addresses of everything it touches.
+        use_graphs = (forced is None and keep_logits is None and self.dev.type == "cuda" and self.dt == BF16
+                      and os.environ.get("SMX_DECODE_GRAPH", "1") != "0")
+        key = (B, S, Lmax, start_id, eos_id, pad_id, self.st.master.data_ptr())
+        dc = getattr(self, "_decode_cache", None)
+        if dc is None:
+            dc = self._decode_cache = {}
+        stt = dc.get(key) if use_graphs else None
+        if stt is None:
+            stt = dict(xkv=[self.new(B * S, 2 * d) for _ in names], cache=[self.zeros(B, Lmax, 2 * d) for _ in names],
+                       logits=self.new(B, Vp, dt=torch.float32), tok=torch.empty(B, dtype=torch.int64, device=self.dev),
+                       nxt=torch.empty(B, dtype=torch.int64, device=self.dev), done=torch.zeros(B, dtype=torch.bool, device=self.dev),
+                       out=torch.empty(B, Lmax, dtype=torch.int64, device=self.dev), lse=self.new(B * H, dt=torch.float32),
+                       pbias=torch.empty(H, Lmax, Lmax, dtype=torch.float32, device=self.dev) if t5 else None,
+                       fin=torch.empty((), dtype=torch.int64, device=self.dev), graphs={}, calls=0, pool=None)
+            if use_graphs:
+                if len(dc) >= 4:                      # a handful of configurations at most (each holds its captured steps)
+                    dc.pop(next(iter(dc)))
+                dc[key] = stt
+        xkv, cache, logits, tok, nxt, done, out, lse, pbias, fin = (stt[k] for k in ("xkv", "cache", "logits", "tok", "nxt", "done",
+                                                                                      "out", "lse", "pbias", "fin"))
+        # cross-attention K/V of every layer, once per call
+        for li, nm in enumerate(names):
+            kn, vn = nm["xattn"]["k"], nm["xattn"]["v"]
+            self.lin(enc, self.st.cat([kn[0], vn[0]]), cat_b(kn, vn), B * S, 2 * d, d, y=xkv[li])
+        if t5:
+            pbias.copy_(self._t5_bias("decoder", Lmax, Lmax)[0])               # [H, Lmax, Lmax]: row t = step t's bias
+        tok.fill_(start_id)
+        done.zero_()
+        out.fill_(pad_id)
+        fin.fill_(-1)                                  # first step after which every clip had emitted eos
+
+        def step(t):
+            """Everything step t does on the device: embed the current tokens, the decoder layers against the caches, the head's
+            arg-max, and the bookkeeping of `out` / `done` / `tok` (a handful of ints; no host round trip)."""
             y = self.new(B, d)
             ops.embed_fwd(tok, self.W(emb_name), y, B, d, escale, self.dt)
             if not t5:
@@ -1484,20 +1505,50 @@ class Engine:
                 y = self.ln_fwd(y, pd + "layer_norm.weight", pd + "layer_norm.bias", B, d, eps)[0]
             ops.gemm(y, self.W(head), logits, B, V, d, self.dt, cv=view(Vp), bias=flb, out_f32=True, alpha=head_alpha)
             ops.cross_entropy(logits, None, None, nxt, None, B, V, Vp, Vp, self.dt)
+            if forced is not None:
+                out[:, t] = nxt
+                tok.copy_(forced[:, t])
+                return
+            # finished rows keep emitting pad
+            out[:, t] = torch.where(done, torch.full_like(nxt, pad_id), nxt)
+            done.logical_or_(nxt == eos_id)
+            tok.copy_(torch.where(done, torch.full_like(nxt, eos_id), nxt))
+            fin.copy_(torch.where((fin < 0) & done.all(), torch.full_like(fin, t), fin))
+
+        # Graph replay (SMX_DECODE_GRAPH=0: off): a step is ~100 launches of 5 - 20 us kernels and the host needs ~2 ms to issue
+        # them, so the decoder is bound by the launch rate.  The first call of a configuration runs eagerly (kernel picks,
+        # one-time launcher set-up); from the second call on, step t is captured once into a HIP graph - positions are launch
+        # parameters, so every t has its own graph - and replayed.  The end-of-sequence test costs a host round trip and is made
+        # every eighth step in that mode (tokens past eos are pad either way).
+        replay = use_graphs and stt["calls"] >= 1
+        stt["calls"] += 1
+        steps = 0
+        for t in range(Lmax):
+            if replay:
+                g = stt["graphs"].get(t)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=stt["pool"]):
+                        step(t)
+                    if stt["pool"] is None:
+                        stt["pool"] = g.pool()
+                    stt["graphs"][t] = g
+                g.replay()
+            else:
+                step(t)
             steps += 1
             if keep_logits is not None:
                 keep_logits.append(logits[:, :V].clone())
             if forced is not None:
-                out[:, t] = nxt
-                tok = forced[:, t].contiguous()
                 continue
-            # bookkeeping on a handful of ints (plumbing): finished rows keep emitting pad
-            out[:, t] = torch.where(done, torch.full_like(nxt, pad_id), nxt)
-            done = done | (nxt == eos_id)
-            tok = torch.where(done, torch.full_like(nxt, eos_id), nxt)
-            if bool(done.all()):
+            if (not replay or (t & 7) == 7 or t == Lmax - 1) and bool(done.all()):
                 break
-        return out[:, :steps], steps
+        if forced is None:
+            f_ = int(fin.item())
+            if f_ >= 0:
+                steps = f_ + 1                         # (replay mode may have run up to seven steps past it: those emitted pad)
+        ids = out[:, :steps].clone()
+        return ids, steps
 
     # ------------------------------------------------------------------ SpeechMixSelf hidden-state matching
     def self_mse(self, enc_s, enc_t, B, S, Lt, want_grad=True):

@@ -340,3 +340,39 @@ def test_persistent_norm_kernels_match_torch_at_any_row_count(M, D, rms, res):
     assert (dg - gr.grad).abs().max().item() <= 2e-5 * gr.grad.abs().max().item() + 1e-4
     if br is not None:
         assert (db - br.grad).abs().max().item() <= 2e-5 * br.grad.abs().max().item() + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["eed_w2v2_bart", "eed_hubert_mbart", "eed_w2v2_t5_trainable"])
+def test_graph_replayed_greedy_decoding_emits_the_eager_tokens(case, monkeypatch):
+    """bf16 greedy decoding replays captured HIP graphs from the second call of a configuration on (Engine.greedy_decode): same
+    tokens as the eager loop (SMX_DECODE_GRAPH=0) - with the real eos id (early stop, checked every eighth step in replay mode)
+    and with eos disabled (every step runs) - on the call that captures, on pure replays, and after the weights changed."""
+    model, inp, gold, m = _build(case, "bf16")
+    wave = inp["input_values"]
+    lc = model.decoder_model.config
+    steps = 12
+    real_eos = lc.eos_token_id
+    for eos in (real_eos, -1):
+        lc.eos_token_id = eos
+        monkeypatch.setenv("SMX_DECODE_GRAPH", "0")
+        want = model.generate(wave, max_length=steps)
+        monkeypatch.setenv("SMX_DECODE_GRAPH", "1")
+        got = [model.generate(wave, max_length=steps) for _ in range(3)]        # eager (first call), capture + replay, replay
+        assert got[0] == want and got[1] == want and got[2] == want, (case, eos, want, got)
+        if eos == -1:
+            assert all(len(g) == steps for g in want)
+    # the graphs hold addresses, not values: new weights in the same storage must show up in the replayed steps
+    with torch.no_grad():
+        for p in model.decoder_model.parameters():
+            p.mul_(1.01)
+    model.store.invalidate()
+    monkeypatch.setenv("SMX_DECODE_GRAPH", "0")
+    want2 = model.generate(wave, max_length=steps)
+    monkeypatch.setenv("SMX_DECODE_GRAPH", "1")
+    assert model.generate(wave, max_length=steps) == want2
+    ntok = torch.randint(4, lc.vocab_size, (2, 9), generator=torch.Generator().manual_seed(2))
+    monkeypatch.setenv("SMX_DECODE_GRAPH", "0")
+    w3 = model.generate_from_text(ntok, max_length=10)
+    monkeypatch.setenv("SMX_DECODE_GRAPH", "1")
+    assert [model.generate_from_text(ntok, max_length=10) for _ in range(2)] == [w3, w3]
