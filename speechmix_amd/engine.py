@@ -1528,8 +1528,20 @@ class Engine:
                 g = stt["graphs"].get(t)
                 if g is None:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=stt["pool"]):
+                    try:
+                        with torch.cuda.graph(g, pool=stt["pool"]):
+                            step(t)
+                    except RuntimeError as e:          # capture refused (a runtime without graph support for some call): stay eager
+                        import warnings
+                        warnings.warn(f"greedy_decode: HIP graph capture failed ({e}); decoding eagerly")
+                        stt["graphs"].clear()
+                        stt["calls"] = -(1 << 30)      # never try again for this configuration
+                        replay = False
                         step(t)
+                        steps += 1
+                        if bool(done.all()):
+                            break
+                        continue
                     if stt["pool"] is None:
                         stt["pool"] = g.pool()
                     stt["graphs"][t] = g

@@ -211,3 +211,49 @@ def test_s3prl_layout_fairseq_namespace_and_empty_loads(tmp_path):
     empty.mkdir()
     with pytest.raises(FileNotFoundError):
         ck.read_checkpoint(str(empty))
+
+
+def test_adafactor_plan_layout_gives_every_partial_sum_its_own_slot():
+    """The fixed-order reductions of the fused Adafactor step (csrc/adafactor.hip) rely on the host plan: a tensor's tiles are
+    contiguous, every row tile owns one row of its segment's [n_rt][C] block of column partials, every column tile one row of
+    its [n_ct][R] block of row sums, and no two tiles (or blocks) overlap in the scratch buffer."""
+    from speechmix_amd.ops import AdafactorPlan
+    shapes = [(768, 3072), (3072, 768), (512, 512, 3), (3072,), (1, 5027), (768, 48, 128), (50265, 768), (100, 4100), (768,), (64, 64)]
+    offs, total = [], 0
+    for s in shapes:
+        offs.append(total)
+        n = 1
+        for d in s:
+            n *= d
+        total += (n + 63) // 64 * 64
+    plan = AdafactorPlan(list(zip(offs, shapes)), torch.device("cpu"))
+    tiles, segs = plan.tiles.tolist(), plan.segs.tolist()
+    import numpy as np
+    tt = np.frombuffer(plan.tensors.numpy().tobytes(), dtype=np.dtype([("off", "<i8"), ("nb", "<i4"), ("R", "<i4"), ("C", "<i4"),
+                                                                       ("row_off", "<i4"), ("col_off", "<i4"), ("rm_off", "<i4"),
+                                                                       ("factored", "<i4"), ("tile0", "<i4"), ("ntile", "<i4"), ("_pad", "<i4")]))
+    used = np.zeros(plan.cpart.numel(), dtype=np.int32)
+    covered = 0
+    for t, T in enumerate(tt):
+        mine = tiles[T["tile0"]:T["tile0"] + T["ntile"]]
+        assert mine and all(tl[0] == t for tl in mine)
+        assert T["tile0"] == covered
+        covered += T["ntile"]
+        if T["factored"]:
+            cells = np.zeros((T["nb"], T["R"], T["C"]), dtype=np.int32)
+            for (_, b, r0, nr, c0, nc, full_rows, full_cols, cp_off, rp_off) in mine:
+                cells[b, r0:r0 + nr, c0:c0 + nc] += 1
+                if not full_cols:
+                    used[cp_off:cp_off + nc] += 1
+                if not full_rows:
+                    used[rp_off + r0:rp_off + r0 + nr] += 1
+            assert (cells == 1).all()                                # the tiles partition every matrix
+    assert covered == len(tiles)
+    assert used.max() <= 1                                           # no slot written twice
+    for (t, b, cp_off, n_rt, rp_off, n_ct) in segs:
+        T = tt[t]
+        if n_rt > 1:
+            assert (used[cp_off:cp_off + n_rt * T["C"]] == 1).all()  # the fold reads exactly what the tiles wrote
+        if n_ct > 1:
+            assert (used[rp_off:rp_off + n_ct * T["R"]] == 1).all()
+        assert n_rt <= AdafactorPlan.MAX_RT
