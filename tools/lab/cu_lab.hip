@@ -35,7 +35,7 @@ struct Res { unsigned long long cyc; unsigned long long rd_bytes, dma_bytes, mfm
 
 // roles: 2 bits per wave (0 idle, 1 R, 2 D, 3 M), wave w at bits 2w
 // src_span: bytes of global memory each CU cycles through (small: L2 hits; large: MALL / HBM)
-template <int INFLIGHT, int MF32>
+template <int INFLIGHT, int MF32, int RTR = 0>     // RTR 1: the R role issues ds_read_b64_tr_b16 (rows-contiguous fragment reads) instead of ds_read_b128
 __global__ __launch_bounds__(1024) void cu_kernel(const char* src, unsigned roles, int budget, unsigned src_span, Res* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) const char* lds_cp_t;
@@ -52,11 +52,25 @@ __global__ __launch_bounds__(1024) void cu_kernel(const char* src, unsigned role
         int it = 0;
         for (;; ++it) {
             if ((it & 3) == 3 && (long long)(__builtin_amdgcn_s_memtime() - t0) > budget) break;
-            const unsigned base = lds0 + ((unsigned)(it + wave) & 7) * 16384u + lane * 16u;
             uint4 v[16];
+            if (RTR == 0) {
+                const unsigned base = lds0 + ((unsigned)(it + wave) & 7) * 16384u + lane * 16u;
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(base), "n"(j * 1024));
+                for (int j = 0; j < 16; ++j)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(base), "n"(j * 1024));
+            } else {
+                // the GEMM's rows-contiguous fragment pattern (gemm_common.h load_frag / rc_addr): lane (g, q, c) reads 8 B of
+                // k-row 8 g + q, 16-column group swizzled by the row; 32 reads of 512 B per batch (same bytes as 16 x b128)
+                const int g = lane >> 4, q = (lane >> 2) & 3, c = lane & 3, kb = 8 * g + q;
+                const unsigned sw = (unsigned)((kb & 3) | (((kb >> 3) & 1) << 2));
+                const unsigned win = lds0 + ((unsigned)(it + wave) & 7) * 16384u + kb * 256u + c * 8u;
+                unsigned long long* w = reinterpret_cast<unsigned long long*>(v);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {           // (16-column group j & 7, k sub-step (j >> 3) & 1, half j >> 4) of a [64 k][128 col] tile
+                    const unsigned addr = win + (unsigned)((((j >> 3) & 1) * 32 + (j >> 4) * 4) * 256) + ((((unsigned)j & 7u) ^ sw) << 5);
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(w[j]) : "v"(addr));
+                }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc ^= v[j].x;
@@ -193,7 +207,7 @@ static unsigned parse_roles(const char* s, int& nw) {
 }
 
 template <int INFLIGHT, int MF32 = 0>
-static void run(const char* roles_s, int iters_r, int iters_d, int iters_m, unsigned span, const char* src, Res* dres, int ncu, int mfma32 = MF32) {
+static void run(const char* roles_s, int iters_r, int iters_d, int iters_m, unsigned span, const char* src, Res* dres, int ncu, int mfma32 = MF32, int rtr = 0) {
     int nw;
     const unsigned roles = parse_roles(roles_s, nw);
     // one iteration count per launch: pick per dominant role so that all roles run for a similar time (fixed by hand below)
@@ -203,7 +217,8 @@ static void run(const char* roles_s, int iters_r, int iters_d, int iters_m, unsi
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((cu_kernel<INFLIGHT, MF32>), dim3(ncu), dim3(64 * nw), 160 * 1024 - 64, 0, src, roles, iters_r, span, dres);
+        if (rtr) hipLaunchKernelGGL((cu_kernel<INFLIGHT, MF32, 1>), dim3(ncu), dim3(64 * nw), 160 * 1024 - 64, 0, src, roles, iters_r, span, dres);
+        else hipLaunchKernelGGL((cu_kernel<INFLIGHT, MF32>), dim3(ncu), dim3(64 * nw), 160 * 1024 - 64, 0, src, roles, iters_r, span, dres);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
     }
@@ -214,12 +229,14 @@ static void run(const char* roles_s, int iters_r, int iters_d, int iters_m, unsi
     double cyc = 0, rd = 0, dm = 0, mf = 0;
     for (auto& r : h) { cyc += (double)r.cyc; rd += (double)r.rd_bytes; dm += (double)r.dma_bytes; mf += (double)r.mfma; }
     cyc /= ncu;
+    if (rtr) printf("[R = ds_read_b64_tr_b16] ");
     printf("%-18s inflight %2d span %8u KB mfma%d: %8.0f cyc (%.1f us, %.2f GHz) | read %6.1f B/clk/CU %6.1f TB/s | dma %6.1f B/clk/CU %6.2f TB/s | mfma pipe %.2f of 4 SIMDs\n",
            roles_s, INFLIGHT, span >> 10, mfma32 ? 32 : 16, cyc, ms * 1e3, cyc / (ms * 1e3) * 1e-3, rd / ncu / cyc, rd / (ms * 1e-3) * 1e-12, dm / ncu / cyc,
            dm / (ms * 1e-3) * 1e-12, mf / ncu / cyc);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool only_tr = argc > 1 && std::string(argv[1]) == "tr";
     int ncu = 256;
     const size_t bytes = (size_t)1 << 30;
     char* src;
@@ -229,7 +246,7 @@ int main() {
     CK(hipMalloc(&dres, sizeof(Res) * 1024));
 
     // 0. store bursts (a GEMM epilogue's 128 KB per CU): issue vs acknowledge, all CUs / one XCD / one CU
-    {
+    if (!only_tr) {
         StRes* sres;
         CK(hipMalloc(&sres, sizeof(StRes) * 256));
         for (int ld : {1536, 6144}) {
@@ -243,6 +260,10 @@ int main() {
     }
     const int IT = 400000;          // shader cycles per launch
     const unsigned L2S = 64u << 10, BIG = 4u << 20;          // per-CU source span: 64 KB (L2-resident) / 4 MB (1 GB chip-wide: HBM)
+    // 5. the rows-contiguous operands' transposing reads (8 B per lane): alone, beside MFMA streams and LDS-DMA
+    for (const char* r : {"R", "RRRR", "RRRRRRRR", "RRRRRRRRRRRRRRRR"}) run<8>(r, IT, 0, 0, L2S, src, dres, ncu, 0, 1);
+    for (const char* r : {"MMMMRRRR", "MMMMMMMMRRRR", "MMMMRRRRRRRRDDDD", "MMMMMMMMRRRRDDDD"}) run<7, 0>(r, IT, 0, 0, L2S, src, dres, ncu, 0, 1);
+    if (only_tr) return 0;
     // 1. LDS reads alone
     for (const char* r : {"R", "RRRR", "RRRRRRRR", "RRRRRRRRRRRRRRRR"}) run<8>(r, IT, 0, 0, L2S, src, dres, ncu, 0);
     // 2. DMA alone: waves, in-flight depth, source
