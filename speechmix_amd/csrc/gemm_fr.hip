@@ -49,10 +49,16 @@ __device__ __forceinline__ constexpr int fr_slot(int blk) { return (PAR && blk >
 //   pass 1:  the fragments of the NEXT half step (k sub-step 1 - PAR of stage `nstage`) are read: column half 0 and the two
 //            spare-slot A blocks at its start, A blocks 0..5 each right after the last MFMA on its slot; ISSUE1: two units.
 // sched_barrier(0) after every A block pins the interleave.
-template <bool A_RC, bool B_RC, int PAR, int CH, bool READ, int ISSUE, int NB, class ISSUER>
+// SMX_FR_LAB (ablation builds, tools/lab/build_variant.sh; results are garbage, only the time means something): 1 = the K loop without
+// its fragment reads (registers keep the item's first fragments), 2 = without its MFMAs.
+#ifndef SMX_FR_LAB
+#define SMX_FR_LAB 0
+#endif
+template <bool A_RC, bool B_RC, int PAR, int CH, bool READ_, int ISSUE, int NB, class ISSUER>
 __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[NB][4], FRFrags<NB>& f, const char* stage, const char* nstage, ISSUER& is, int tid,
                                         int lane, int wr, int wc) {
-    if constexpr (CH == 0) {
+    constexpr bool READ = READ_ && SMX_FR_LAB != 1;
+    if constexpr (CH == 0 && SMX_FR_LAB != 1) {
         f.b[1][0] = fr_bfrag<B_RC>(stage, 1, 0, PAR, wc, lane);
         f.b[1][1] = fr_bfrag<B_RC>(stage, 1, 1, PAR, wc, lane);
     } else if constexpr (READ) {
@@ -66,8 +72,10 @@ __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[NB][4], FRFrags<NB>& f, c
     for (int g = 0; g < NB; ++g) {
         const int sl = fr_slot<PAR, NB>(g);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            acc[g][CH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[CH][j], f.a[sl], acc[g][CH * 2 + j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (SMX_FR_LAB != 2) acc[g][CH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b[CH][j], f.a[sl], acc[g][CH * 2 + j], 0, 0, 0);
+            else asm volatile("" : "+v"(f.a[sl]), "+v"(f.b[CH][j]));            // (keeps the fragment reads alive)
+        }
         if constexpr (CH == 1 && READ) {
             if (g < NB - 2) f.a[g] = fr_afrag<A_RC, NB>(nstage, g, 1 - PAR, wr, lane);
         }
