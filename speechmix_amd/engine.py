@@ -175,6 +175,7 @@ class Engine:
         if getattr(self, "_side_active", False):          # join the LM stage's weight-gradient stream
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_active = False
+            ops.GEMM_CONCURRENT = False
         if self.folds is not None:
             self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
         if self.stage_cb is not None:
@@ -295,35 +296,34 @@ class Engine:
                      split_k=split, split_stride=n, alpha=alpha, tr_mode=mode, **kw)
             ops.reduce_slabs(slabs, split, n, n, out, accumulate=accumulate)
 
-        pick = 0
+        choice = cands[0]
         if len(cands) > 1:
+            # the pick is stored as the chosen (kernel, K split) itself: the candidate list depends on SMX_GEMM_PP / SMX_GEMM_FR /
+            # the stream, so a positional index from a picks file written under other settings could name another kernel
             key = ("wgrad", ops.pp_cus(), No, Ko, Kred, av.rows_per_batch > 0, bv.rows_per_batch > 0, tuple(sorted(kw)))
-            pick = ops._tuned_get(key)
-            if pick is None:
-                pick = 0
+            choice = ops._tuned_get(key)
+            if isinstance(choice, list):
+                choice = tuple(choice)
+            if choice not in cands:                          # nothing stored, or a pick that is not on offer here: tune
+                choice = cands[0]
                 if all(sp > 1 for _, sp in cands):          # slab launches only: re-running them changes nothing
-                    ts = []
-                    for mode, sp in cands:
+                    def once(mode, sp):
                         slabs = self.workspace(self._slab_key(), sp * n, torch.float32)
 
-                        def once():
+                        def f():
                             ops.gemm(dy, x, slabs, No, Ko, Kred, self.dt, a_rc=True, b_rc=True, av=av, bv=bv, cv=cv, out_f32=True,
                                      atomic=0, split_k=sp, split_stride=n, alpha=alpha, tr_mode=mode, **kw)
-                            ops.reduce_slabs(slabs, sp, n, n, slabs, accumulate=False)
-                        once()
-                        torch.cuda.synchronize()
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        for _ in range(3):
-                            once()
-                        e1.record()
-                        torch.cuda.synchronize()
-                        ts.append(e0.elapsed_time(e1))
-                    pick = min(range(len(ts)), key=lambda i: ts[i] * (1.0 if i == 0 else 1.03))      # ties go to the 128x128 kernel
+                            ops._reduce_slabs(slabs, sp, n, n, slabs, False)
+                        return f
+                    self.workspace(self._slab_key(), max(sp for _, sp in cands) * n, torch.float32)      # (grown once, before timing)
+                    ts = ops.measure_candidates({c: once(*c) for c in cands})
+                    choice = min(ts, key=lambda c: ts[c] * (1.0 if c == cands[0] else 1.03))      # ties go to the 128x128 kernel
+                    ops.TUNE_LIVE_KEYS.append(key)
                     if ops.TUNE_LOG is not None:
-                        ops.TUNE_LOG.append((key, ts[0] / 3, ts[1] / 3, cands[pick], None, None, ts[2] / 3 if len(ts) > 2 else None))
-                ops._tuned_set(key, pick)
-        run(*cands[pick])
+                        ops.TUNE_LOG.append((key, ts.get(cands[0]), ts.get(cands[1]), choice, None, None,
+                                             ts.get(cands[2]) if len(cands) > 2 else None))
+                ops._tuned_set(key, choice)
+        run(*choice)
 
     def wgrad(self, dy, x, gw, M, N, K, dyv=None, xv=None, alpha=1.0, gb=None, dy_ld=None, side_ok=True, **kw):
         """gw[N,K] += dy[M,N]^T @ x[M,K];  gb[N] += colsum(dy).  The reduction over M is split across workgroups
@@ -437,19 +437,9 @@ class Engine:
             if mode is None:
                 mode = 8
                 if len(outs) == len(probs):            # slab launches only: re-running them changes nothing
-                    ts = {}
-                    for _ in range(2):
-                        for m in (8, 12):
-                            ops.gemm_group(probs, self.dt, mode=m)
-                            torch.cuda.synchronize()
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for _ in range(3):
-                                ops.gemm_group(probs, self.dt, mode=m)
-                            e1.record()
-                            torch.cuda.synchronize()
-                            ts[m] = min(ts.get(m, 1e9), e0.elapsed_time(e1) / 3)
+                    ts = ops.measure_candidates({m: (lambda m=m: ops.gemm_group(probs, self.dt, mode=m)) for m in (8, 12)})
                     mode = 12 if ts[12] < ts[8] else 8
+                    ops.TUNE_LIVE_KEYS.append(key)
                     if ops.TUNE_LOG is not None:
                         ops.TUNE_LOG.append((key, None, ts[8], mode, None, None, ts[12]))
                 ops._tuned_set(key, mode)
@@ -1870,6 +1860,7 @@ class Engine:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream()
             self._side_active = True
+            ops.GEMM_CONCURRENT = True
         return self.lm_bwd(dlogits, lsv, gscale, extra_denc=extra_denc)
 
     def _backward(self, gscale, zero_grads):

@@ -654,6 +654,9 @@ class SpeechMixEED(nn.Module):
             return_dict["encoder_last_hidden_state"] = out["enc_last"].view(B, T, d).float()
             return_dict["inputs_embeds"] = out["inputs_embeds"].view(B, S, dd).float()
             return_dict["lm_encoder_last_hidden"] = out["lm_enc_last"].view(B, S, dd).float()
+            # (round 4) what HF returns with output_hidden_states=True: the L + 1 encoder hidden states; and the adapters' output
+            return_dict["encoder_hidden_states"] = tuple(h.view(B, T, d).float() for h in out["hidden"])
+            return_dict["post_adapter"] = out["post_adapter"].view(B, -1, d).float()
             if out.get("sw") is not None:
                 return_dict["weighted_sum"] = out["sw"]
             for k, v in out.get("parts", {}).items():

@@ -65,10 +65,16 @@ def _gemm_params(a, b, c, M, N, K, a_rc=False, b_rc=False, av=None, bv=None, cv=
 PP_MODE = os.environ.get("SMX_GEMM_PP", "auto")
 _TUNED = {}
 # Kernel picks decide the K split and with it the fp32 summation order: bf16 results are bit-reproducible across processes only
-# with the same picks.  SMX_TUNE_FILE=path loads picks at start-up and writes new ones back at exit (JSON, keys as repr
-# strings); tuner_state() / load_tuner_state() carry them between ranks (StepRunner broadcasts rank 0's).
+# with the same picks, and a bench line is reproducible across boxes only with the same kernels.  Round 4: the picks of the
+# benchmarked configurations ship IN-TREE (speechmix_amd/tune/mi355x_picks.json, measured on an MI355X with tools/make_picks.sh) and
+# are loaded by default; keys the file does not hold are tuned live (medians of interleaved launches, below).  SMX_TUNE=live
+# ignores the shipped file; SMX_TUNE_FILE=path loads picks from `path` (on top of the shipped ones unless SMX_TUNE=live) and
+# writes every pick made by this process back at exit (JSON, keys as repr strings); tuner_state() / load_tuner_state() carry
+# them between ranks (StepRunner broadcasts rank 0's).
 _TUNE_FILE = os.environ.get("SMX_TUNE_FILE", "")
+_TUNE_SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune", "mi355x_picks.json")
 _TUNE_DIRTY = False
+TUNE_LIVE_KEYS = []          # keys that had to be tuned live in this process (bench.py reports their count)
 
 
 def _tuned_get(key):
@@ -91,10 +97,15 @@ def load_tuner_state(state):
 
 
 def _tune_file_load():
-    if _TUNE_FILE and os.path.exists(_TUNE_FILE):
-        import json
-        with open(_TUNE_FILE) as f:
-            _TUNED.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in json.load(f).items()})
+    import json
+    paths = [] if os.environ.get("SMX_TUNE", "") == "live" else [_TUNE_SHIPPED]
+    if _TUNE_FILE:
+        paths.append(_TUNE_FILE)
+    for path in paths:
+        if os.path.exists(path):
+            with open(path) as f:
+                _TUNED.update({k: (tuple(v) if isinstance(v, list) else v) for k, v in json.load(f).items()
+                               if not k.startswith("_")})
 
 
 def _tune_file_save():
@@ -180,17 +191,47 @@ def _launch(p, dtype):
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
 
 
-def _time_mode(p, dtype, mode, reps=3):
-    p.tr_mode = mode
-    _launch(p, dtype)
+TUNE_ROUNDS = int(os.environ.get("SMX_TUNE_ROUNDS", "5"))
+
+
+def measure_candidates(runs, rounds=None, reps=2):
+    """Live timing of alternative launches of ONE piece of work: runs = {candidate: callable that enqueues it}.  Every candidate
+    is warmed once, then `rounds` interleaved rounds time `reps` back-to-back launches of each; a candidate's figure is the
+    MEDIAN of its samples after dropping those above twice its fastest (the ~1.8-ms single-launch outliers of this pool,
+    DESIGN.md 6b).  A candidate whose launch raises RuntimeError (a class the variant is not instantiated for) is left out.
+    -> {candidate: milliseconds per launch}."""
+    rounds = rounds or TUNE_ROUNDS
+    ok = []
+    for c, run in runs.items():
+        try:
+            run()
+            ok.append(c)
+        except RuntimeError:
+            continue
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    samples = {c: [] for c in ok}
+    evs = {c: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(rounds)] for c in ok}
+    for r in range(rounds):
+        for c in ok:
+            e0, e1 = evs[c][r]
+            e0.record()
+            for _ in range(reps):
+                runs[c]()
+            e1.record()
+    torch.cuda.synchronize()
+    out = {}
+    for c in ok:
+        ts = sorted(e0.elapsed_time(e1) / reps for e0, e1 in evs[c])
+        ts = [t for t in ts if t <= 2.0 * ts[0]]
+        out[c] = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+    return out
+
+
+def _run_mode(p, dtype, mode):
+    def run():
+        p.tr_mode = mode
         _launch(p, dtype)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return run
 
 
 HALF_MODE = os.environ.get("SMX_GEMM_HALF", "auto")      # 64 x 128 tiles of the 128x128 kernel (tr_mode 9): auto | 0 | 1
@@ -252,15 +293,9 @@ def _choose_mode(p, dtype):
         safe = p.atomic == 0 and p.resid != p.C and p.aux_in != p.C and p.A != p.C and p.B != p.C
         mode = 1
         if safe:
-            times = {}
-            for _ in range(2):                    # two interleaved passes, best of each candidate: single passes flip near-ties
-                for m in cands:
-                    try:
-                        t = _time_mode(p, dtype, m)
-                    except RuntimeError:          # a class the variant is not instantiated for
-                        continue
-                    times[m] = min(times.get(m, t), t)
+            times = measure_candidates({m: _run_mode(p, dtype, m) for m in cands})
             mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else _TUNE_MARGIN))      # ties go to the 128x128 kernel
+            TUNE_LIVE_KEYS.append(key)
             if TUNE_LOG is not None:
                 TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11), times.get(12), times.get(13)))
         _tuned_set(key, mode)
@@ -283,9 +318,33 @@ def gemm(a, b, c, M, N, K, dtype, **kw):
         e0.record()
         _launch(p, dtype)
         e1.record()
-        prof.add((p.a_rc, p.b_rc, p.tr_mode & 255), e0, e1, 2.0 * M * N * K * p.nbatch, (M, N, K, p.nbatch, p.split_k))
+        prof.add((p.a_rc, p.b_rc, p.tr_mode & 255), e0, e1, 2.0 * M * N * K * p.nbatch, (M, N, K, p.nbatch, p.split_k),
+                 _gemm_bytes(p, dtype))
         return
     _launch(p, dtype)
+
+
+def _gemm_bytes(p, dtype):
+    """ALGORITHMIC bytes of one GEMM launch: every distinct operand element read once, every output element written once
+    (fp32 slabs: one per K slice), side tensors of the epilogue once.  An overlapping row view (a Conv1d window: rows
+    `ld` apart, K > ld elements long) counts its distinct elements, not rows x K."""
+    es = 2 if dtype == BF16 else 4
+
+    def operand(v, rows, k, rc):
+        if rc:                      # rows-contiguous: [k, rows] with leading dimension ld over k
+            return rows * k
+        if v.rows_per_batch > 0 and 0 < abs(v.ld) < k:
+            nb = (rows + v.rows_per_batch - 1) // v.rows_per_batch
+            return nb * ((v.rows_per_batch - 1) * abs(v.ld) + k)
+        return rows * k
+    a = operand(p.a, p.M, p.K, p.a_rc)
+    b = operand(p.b, p.N, p.K, p.b_rc)
+    mn = p.M * p.N
+    c = mn * (4 * max(p.split_k, 1) if p.out_f32 else es)
+    if p.atomic == 2:
+        c += mn * 4                 # accumulate: the destination is read as well
+    side = mn * es * (bool(p.resid) + bool(p.aux_out) + bool(p.aux_in))
+    return float(p.nbatch) * ((a + b) * es + c + side)
 
 
 def pp_split(Mo, No, Kred):
@@ -313,14 +372,18 @@ def gemm_splitk(a, b, c, M, N, K, dtype, split, slabs, **kw):
 
 class GemmProfile:
     """Live per-launch timing of the GEMM kernel variants with HIP events on the launch stream (bench.py).
-    Variants: (a_rc, b_rc) = (0,0) forward, (0,1) data gradient, (1,1) weight gradient."""
+    Variants: (a_rc, b_rc) = (0,0) forward, (0,1) data gradient, (1,1) weight gradient.  Every record carries the launch's
+    flops, its ALGORITHMIC bytes (_gemm_bytes), the engine's tag and whether a second compute stream was active beside it
+    (the LM stage's weight-gradient stream: durations then include the contention)."""
     _ROLE = {(0, 0): "fwd", (0, 1): "dgrad", (1, 1): "wgrad", (1, 0): "rc_kc"}
+    FAMILY = {1: "gemm_bf16_dma_kernel", 9: "gemm_bf16_dma_kernel", 11: "gemm_bf16_dma8_kernel", 8: "gemm_bf16_pp_kernel",
+              12: "gemm_bf16_fr_kernel", 13: "gemm_bf16_fr_kernel"}
 
     @staticmethod
     def name(key):
         a, b, mode = key
-        kern = "gemm_bf16_pp_kernel" if mode == 8 else "gemm_bf16_fr_kernel" if mode in (12, 13) else "gemm_bf16_dma_kernel"
-        tile = ", 64x128 tiles" if mode == 9 else ", 256x128 tiles" if mode == 11 else ", 192x256 tiles" if mode == 13 else ""
+        kern = GemmProfile.FAMILY.get(mode, "gemm_bf16_dma_kernel")
+        tile = ", 64x128 tiles" if mode == 9 else ", 192x256 tiles" if mode == 13 else ""
         return f"{kern}<{str(bool(a)).lower()},{str(bool(b)).lower()}> ({GemmProfile._ROLE[(a, b)]}{tile})"
 
     def __init__(self):
@@ -333,27 +396,61 @@ class GemmProfile:
         self.used += 2
         return e
 
-    def add(self, key, e0, e1, flops, shape=None):
-        self.recs.append((key, e0, e1, flops, shape))
+    def add(self, key, e0, e1, flops, shape=None, nbytes=0.0):
+        self.recs.append((key, e0, e1, flops, shape, nbytes, GEMM_CONCURRENT))
         self.tags.append(GEMM_TAG)
+
+    def _groups(self, pick=lambda rec, tag: True):
+        """{(variant, shape): [ms, ...]} plus per-group flops / bytes per launch, over the records `pick` accepts."""
+        out = {}
+        for rec, tag in zip(self.recs, self.tags):
+            if not pick(rec, tag):
+                continue
+            key, e0, e1, fl, shape, nb, conc = rec
+            g = out.setdefault((key, shape), dict(ms=[], flops=fl, bytes=nb))
+            g["ms"].append(e0.elapsed_time(e1))
+        return out
+
+    @staticmethod
+    def _median(v):
+        v = sorted(v)
+        n = len(v)
+        return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+    def robust(self, pick=lambda rec, tag: True):
+        """Outlier-proof totals: every (variant, shape) group contributes launches x its MEDIAN duration (single launches of
+        ~1.8 ms appear once per few hundred steps on this pool).  -> dict(launches, total_ms, flops, bytes, tflops)."""
+        d = dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0)
+        for g in self._groups(pick).values():
+            n = len(g["ms"])
+            d["launches"] += n
+            d["total_ms"] += n * self._median(g["ms"])
+            d["flops"] += n * g["flops"]
+            d["bytes"] += n * g["bytes"]
+        d["tflops"] = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["total_ms"] > 0 else 0.0
+        return d
 
     def by_tag(self, tag):
         """Launches recorded while ops.GEMM_TAG == tag (the engine tags the speech encoder's transformer layers "enc_layer":
         their Linear forward / data-gradient / weight-gradient GEMMs are what north_star's 0.40 is defined on):
-        -> dict(launches, total_ms, flops, tflops)."""
-        d = dict(launches=0, total_ms=0.0, flops=0.0)
-        for (key, e0, e1, fl, _), t in zip(self.recs, self.tags):
-            if t == tag:
-                d["launches"] += 1
-                d["total_ms"] += e0.elapsed_time(e1)
-                d["flops"] += fl
-        d["tflops"] = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["total_ms"] > 0 else 0.0
-        return d
+        -> dict(launches, total_ms, flops, tflops), medians per (variant, shape)."""
+        return self.robust(lambda rec, t: t == tag)
+
+    def families(self):
+        """{kernel family: robust totals + launches that ran beside the second stream} - the fixed rule bench.py nominates its
+        roofline kernel by: the family with the largest share of the GEMM flops."""
+        out = {}
+        for fam in sorted(set(self.FAMILY.values())):
+            d = self.robust(lambda rec, t: self.FAMILY.get(rec[0][2]) == fam)
+            if d["launches"]:
+                d["concurrent_launches"] = sum(1 for rec in self.recs if self.FAMILY.get(rec[0][2]) == fam and rec[6])
+                out[fam] = d
+        return out
 
     def by_shape(self):
         """-> {(variant, (M, N, K, nbatch, split_k)): dict(launches, total_ms, flops)} (tools/gpu_gemm_shapes.py)."""
         out = {}
-        for key, e0, e1, fl, shape in self.recs:
+        for key, e0, e1, fl, shape, nb, conc in self.recs:
             d = out.setdefault((key, shape), dict(launches=0, total_ms=0.0, flops=0.0))
             d["launches"] += 1
             d["total_ms"] += e0.elapsed_time(e1)
@@ -361,21 +458,19 @@ class GemmProfile:
         return out
 
     def summary(self):
-        """-> {variant: dict(launches, total_ms, avg_us, flops, tflops)}; call after a device synchronize."""
+        """-> {variant: dict(launches, total_ms, avg_us, median_us, flops, bytes, tflops)}; totals are launches x median per
+        (variant, shape) group.  Call after a device synchronize."""
         out = {}
-        for key, e0, e1, fl, _ in self.recs:
-            d = out.setdefault(key, dict(launches=0, total_ms=0.0, flops=0.0))
-            d["launches"] += 1
-            d["total_ms"] += e0.elapsed_time(e1)
-            d["flops"] += fl
-        for d in out.values():
+        for key in sorted({rec[0] for rec in self.recs}):
+            d = self.robust(lambda rec, t: rec[0] == key)
             d["avg_us"] = 1e3 * d["total_ms"] / d["launches"]
-            d["tflops"] = d["flops"] / (d["total_ms"] * 1e-3) / 1e12 if d["total_ms"] > 0 else 0.0
+            out[key] = d
         return out
 
 
 GEMM_PROFILE = None
 GEMM_TAG = None          # set by the engine around stages whose GEMMs a report singles out (bench.py: encoder_gemms)
+GEMM_CONCURRENT = False  # set by the engine while a second compute stream runs beside the launches (LM stage of backward)
 
 
 class OpProfile:
@@ -869,10 +964,11 @@ def gemm_group(problems, dtype, mode=8):
     """ONE persistent launch of the 256x256 kernel over up to 4 weight-gradient problems (smx_gemm_group).  problems: list of
     (a, b, c, M, N, K, kw) with the arguments of `gemm` (a_rc = b_rc = True, out_f32, plain views)."""
     arr = (L.GemmParams * len(problems))()
-    flops = 0.0
+    flops = nbytes = 0.0
     for i, (a, b, c, M, N, K, kw) in enumerate(problems):
         arr[i] = _gemm_params(a, b, c, M, N, K, **kw)
         flops += 2.0 * M * N * K
+        nbytes += _gemm_bytes(arr[i], dtype)
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = prof.events()
@@ -882,7 +978,7 @@ def gemm_group(problems, dtype, mode=8):
     if prof is not None:
         e1.record()
         a, b, c, M, N, K, kw = problems[0]
-        prof.add((1, 1, mode), e0, e1, flops, ("group", len(problems), K, 1, kw.get("split_k", 1)))
+        prof.add((1, 1, mode), e0, e1, flops, ("group", len(problems), K, 1, kw.get("split_k", 1)), nbytes)
 
 
 def reduce_slabs_many(items, accumulate=True):

@@ -10,7 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def manifest():
     out = {}
-    for name in ("manifest.json", "manifest_r2.json", "manifest_r3.json"):      # later rounds' fixtures live beside round 1's
+    for name in ("manifest.json", "manifest_r2.json", "manifest_r3.json", "manifest_r4.json"):      # later rounds' fixtures live beside round 1's
         path = os.path.join(GOLDEN, name)
         if os.path.exists(path):
             with open(path) as f:

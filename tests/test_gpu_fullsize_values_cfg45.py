@@ -34,9 +34,16 @@ def test_full_dimension_values_fp32_and_bf16_against_the_oracle_yardstick(cfg, N
     r16, _ = run(cfg, "bf16", 2, N, 8, ref)
     y = ref["bf16"]
     print(f"[cfg {cfg} bf16] " + ", ".join(f"{k} {r16[k]:.3e} (oracle-bf16 {y[k]:.3e})" for k in
-                                           ("raw_logits", "encoder_last_hidden_state", "inputs_embeds", "loss", "grad_worst")))
-    for k in ("raw_logits", "encoder_last_hidden_state", "inputs_embeds", "grad_worst"):
-        assert r16[k] <= 1.5 * y[k], (k, r16[k], y[k], r16.get("grad_worst_name"))
+                                           ("raw_logits", "encoder_last_hidden_state", "inputs_embeds", "loss", "grad_worst", "grad_worst_l2")))
+    # round 4: the relative-L2 gradient criterion of the fp32 leg in bf16 too (the max-entry criterion alone is vacuous where the
+    # yardstick itself is ~0.5 of a tensor's max: config 4), and the loss
+    for k in ("raw_logits", "encoder_last_hidden_state", "inputs_embeds", "grad_worst", "grad_worst_l2"):
+        assert r16[k] <= 1.5 * y[k], (k, r16[k], y[k], r16.get(k + "_name"))
+    # Loss: a mean of (log-sum-exp - label logit) over <= 16 tokens, so its error is bounded by the logits' error; the
+    # oracle-bf16's own loss error is ONE draw of a scalar that cancels to anywhere between 0 and that bound (round 3 measured
+    # 2.5e-4 for config 4 where the HIP path had 4.1e-3 - both far inside the logits' 3e-2 ... 6e-2), so the yardstick is the
+    # larger of 1.5 x that draw and a quarter of the logits' allowance.
+    assert r16["loss"] <= max(1.5 * y["loss"], 0.25 * 1.5 * y["raw_logits"]), (r16["loss"], y["loss"], y["raw_logits"])
     assert r16["argmax_checked"] > 0 and r16["argmax_equal"]
     del ref
     torch.cuda.empty_cache()

@@ -97,3 +97,26 @@ def test_adapter_oracle_is_identity_free_and_indexed_per_layer():
     ref = torch.relu(h @ ad["adapters.1.1.weight"].t() + ad["adapters.1.1.bias"]) @ ad["adapters.1.3.weight"].t() \
         + ad["adapters.1.3.bias"]
     assert torch.allclose(y, ref, atol=1e-6)
+
+
+def test_adapter_oracle_matches_the_reference_class_with_bound_hooks():
+    """Round 4: `oracle.lm_adapter` against the reference's own HFSpeechMixAdapter (ref:speechmix/hf_model.py:456-500) run by
+    tests/golden/make_golden_r4.py with its forward hooks re-registered so that LM layer i applies adapter i - the indexing the
+    restatement documents as the intent (as written the reference's lambdas all run the last adapter)."""
+    from tests.golden_util import load_case
+    sd, inp, gold, m = load_case("adapter_tiny")
+    leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()
+              if not k.endswith(("embed_tokens.weight", "lm_head.weight"))}
+    out = O.speechmix_eed_forward(leaves, m["enc_cfg"], m["lm_cfg"], inp["input_values"], labels=inp["labels"],
+                                  down_scale=m["down_scale"])
+    assert (out["raw_logits"] - gold["raw_logits"]).abs().max().item() <= 2e-5
+    assert abs(out["loss"].item() - gold["loss"].item()) <= 2e-5
+    assert torch.equal(out["logits"], gold["logits"])
+    out["loss"].backward()
+    n = 0
+    for k, g in gold.items():
+        if k.startswith("grad::"):
+            e = (leaves[k[6:]].grad - g).abs().max().item()
+            assert e <= 2e-5 * max(1.0, g.abs().max().item()), (k, e)
+            n += 1
+    assert n >= 6

@@ -122,14 +122,19 @@ def oracle_vs_oracle(leaves16, r16, leaves32, r32):
         return (a.detach().float() - b.detach().float()).abs().max().item()
     res = {k: err(r16[k], r32[k]) for k in ("encoder_last_hidden_state", "inputs_embeds", "raw_logits")}
     res["loss"] = abs(float(r16["loss"]) - float(r32["loss"]))
-    worst = ("", 0.0)
+    worst, worst2 = ("", 0.0), ("", 0.0)
     gmax = max(float(v.grad.abs().max()) for v in leaves32.values() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None)
     for k, v in leaves32.items():
         if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None and leaves16[k].grad is not None:
-            e = err(leaves16[k].grad, v.grad) / max(v.grad.abs().max().item(), 1e-3 * gmax)
+            g = v.grad.float()
+            e = err(leaves16[k].grad, g) / max(g.abs().max().item(), 1e-3 * gmax)
+            e2 = (leaves16[k].grad.float() - g).norm().item() / max(g.norm().item(), 1e-3 * gmax * g.numel() ** 0.5)
             if e > worst[1]:
                 worst = (k, e)
+            if e2 > worst2[1]:
+                worst2 = (k, e2)
     res["grad_worst"], res["grad_worst_name"] = worst[1], worst[0]
+    res["grad_worst_l2"], res["grad_worst_l2_name"] = worst2[1], worst2[0]
     return res
 
 
