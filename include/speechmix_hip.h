@@ -162,11 +162,19 @@ int smx_sizeof_SmxFoldTable(void);
 int smx_cast_from_f32(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 int smx_cast_to_f32(const void* src, float* dst, long long n, int dtype, hipStream_t stream);
 int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k, int dtype, hipStream_t stream);
+/* Conv1d weight [Co, Ci, k] -> the K-contiguous data-gradient operands of its `stride` input residues, back to back:
+ * Wd_r[ci, c * Co + co] = w[co, ci, r + (nj_r - 1 - c) * stride] (the backward of TF:models/wav2vec2/modeling_wav2vec2.py:254-323's
+ * strided convolutions as forward-layout GEMMs over runs of the output gradient) */
+int smx_pack_conv_w_dgrad(const float* w, void* out, int Co, int Ci, int k, int stride, int dtype, hipStream_t stream);
 int smx_unpack_conv_dw(const float* dwp, float* dw, int Co, int Ci, int k, hipStream_t stream);
 int smx_act_bwd(const void* dy, const void* pre, void* dx, int M, int N, const SmxRowView* out_view, int act, int dtype, hipStream_t stream);
 int smx_mask_rows(void* x, const int* rows, int nrows, const float* emb, int D, int dtype, hipStream_t stream);
 int smx_mask_rows_bwd(void* dx, const int* rows, int nrows, float* demb, int D, int dtype, hipStream_t stream);
 int smx_add(const void* a, const void* b, void* out, long long n, int dtype, hipStream_t stream);
+/* base[table[2 i] + j] = 0 for j < table[2 i + 1], i < n (device table of element offset / count pairs, counts <= 65536): the
+ * step's gradient zeroing restricted to the ranges no first-writer stores (what `optimizer.zero_grad()` / DDP's bucket reset do
+ * around ref:train.py:291-330 for the whole 942-MB buffer; round 4: the weight-gradient GEMMs' first write of a step stores). */
+int smx_zero_ranges(float* base, const long long* table, int n, hipStream_t stream);
 /* SpeechMixSelf hidden-state matching (ref:speechmix/model.py:247-255): row softmax fwd/bwd, MSE (+gradient), fp32 -> T add */
 int smx_softmax_rows(float* x, int R, int Cn, hipStream_t stream);
 int smx_softmax_rows_bwd(const float* p, const float* dp, float* dx, int R, int Cn, float scale, hipStream_t stream);

@@ -4,8 +4,8 @@ The classes mirror what `from speechmix import *` gives the reference's train.py
 ref:train.py:190-225); they are imported lazily so that `import speechmix_amd` stays light (no kernels are loaded until a
 model is built).
 """
-__all__ = ["SpeechMixEED", "SpeechMixFixed", "SpeechMixAdapter", "SpeechMixSelf", "shift_tokens_right",
-           "handle_decoder_input_none"]
+__all__ = ["SpeechMixEED", "SpeechMixFixed", "SpeechMixAdapter", "SpeechMixSelf", "HFSpeechMixEED", "HFSpeechMixFixed",
+           "HFSpeechMixAdapter", "HFSpeechMixSelf", "shift_tokens_right", "handle_decoder_input_none"]
 
 
 def __getattr__(name):

@@ -244,6 +244,7 @@ int smx_gemm_fr(const SmxGemmParams& pin, hipStream_t stream) {
 #define FR_GO(AR, BR, E) { if (epi == E) p.tr_mode |= 128; if (mt == 192) fr_launch<AR, BR, E, 192>(p, grid, stream); else fr_launch<AR, BR, E, PP_BM>(p, grid, stream); SMX_CHECK_LAUNCH(); }
     if (!p.a_rc && !p.b_rc) {
         if (epi == PP_EPI_ACT) FR_GO(false, false, PP_EPI_ACT)
+        if (epi == PP_EPI_ACTGRAD) FR_GO(false, false, PP_EPI_ACTGRAD)      // (round 4: conv data gradients through transposed taps)
         if (epi == PP_EPI_F32) FR_GO(false, false, PP_EPI_F32)
         FR_GO(false, false, PP_EPI_LINEAR)
     }

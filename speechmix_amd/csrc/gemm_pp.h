@@ -44,7 +44,7 @@ __device__ __forceinline__ const SmxGemmParams& pp_kernarg() {
 // their work items are concatenated (problem g owns items wstart[g] .. wstart[g+1]-1 of the launch).  A layer's four weight
 // gradients then fill the chip with TWO K slices per output tile instead of seven each, which cuts the slab traffic of the
 // split-K reduction 3.5x and four launches (+ their tails) to one.
-#define PP_MAXG 4
+#define PP_MAXG 8            // (round 4: a decoder layer has seven weight gradients; 8 x 288 B of parameter blocks fit the 4-KB kernarg segment)
 struct SmxGemmGroup {
     int count, W;
     int wstart[PP_MAXG + 1];

@@ -67,6 +67,36 @@ extern "C" int smx_pack_conv_w(const float* w, void* out, int Co, int Ci, int k,
     else return SMX_EINVAL;
     SMX_CHECK_LAUNCH();
 }
+// Data-gradient operands of a strided Conv1d (round 4).  The gradient wrt input position t = u s + r (residue r) sums the taps
+// j s + r: dX[t, ci] = sum_j sum_co dPre[u - j, co] w[co, ci, j s + r] - a GEMM whose A rows are the contiguous runs
+// dPre[u - (nj - 1) .. u] (nj = taps of that residue) and whose B operand, K-CONTIGUOUS, is
+//     Wd_r[ci, c Co + co] = w[co, ci, r + (nj - 1 - c) s],   c = 0 .. nj - 1.
+// out = the s matrices [Ci, nj_r Co] back to back (residue r starts at Ci Co x taps of residues < r).  With them the data
+// gradients run in the forward's (K-contiguous, K-contiguous) layout on the 256-wide kernels instead of reading the
+// tap-major forward weight rows-contiguous through a batched view.
+template <typename T>
+__global__ void pack_conv_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int k, int s) {
+    const long long n = (long long)Co * Ci * k;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int t = i % k, ci = (i / k) % Ci, co = i / ((long long)Ci * k);
+        const int r = t % s, j = t / s;
+        const int nj = (k - r + s - 1) / s;
+        int before = 0;                       // taps of the residues below r
+        for (int q = 0; q < r; ++q) before += (k - q + s - 1) / s;
+        const long long dst = (long long)Ci * Co * before + ((long long)ci * nj + (nj - 1 - j)) * Co + co;
+        Cvt<T>::st(out + dst, w[i]);
+    }
+}
+extern "C" int smx_pack_conv_w_dgrad(const float* w, void* out, int Co, int Ci, int k, int s, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!w || !out || Co <= 0 || Ci <= 0 || k <= 0 || s <= 0 || s > k) return SMX_EINVAL;
+    const long long n = (long long)Co * Ci * k;
+    int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(pack_conv_w_dgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, w, (bf16_t*)out, Co, Ci, k, s);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(pack_conv_w_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, (float*)out, Co, Ci, k, s);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
 // dW (tap-major fp32 [Co, k*Ci]) accumulated into the parameter-layout gradient [Co, Ci, k]
 __global__ void unpack_conv_dw_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int k) {
     const long long n = (long long)Co * Ci * k;
@@ -568,6 +598,27 @@ extern "C" int smx_add(const void* a, const void* b, void* out, long long n, int
     if (dtype == SMX_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)out, n);
     else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- zeroing of scattered ranges of the flat gradient
+// one block per table row (offset, count <= 65536): 16-B stores over the aligned interior, scalar head / tail
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const long long* table) {
+    const long long off = table[2 * blockIdx.x], cnt = table[2 * blockIdx.x + 1];
+    float* p = base + off;
+    const long long head = min(cnt, (long long)((4 - (off & 3)) & 3));
+    if ((long long)threadIdx.x < head) p[threadIdx.x] = 0.f;
+    const long long nvec = (cnt - head) >> 2;
+    float4* v = reinterpret_cast<float4*>(p + head);
+    for (long long i = threadIdx.x; i < nvec; i += 256) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long done = head + (nvec << 2);
+    if (done + threadIdx.x < cnt) p[done + threadIdx.x] = 0.f;
+}
+extern "C" int smx_zero_ranges(float* base, const long long* table, int n, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0) return 0;
+    if (!base || !table || ((size_t)base & 15)) return SMX_EINVAL;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(n), dim3(256), 0, stream, base, table);
     SMX_CHECK_LAUNCH();
 }
 

@@ -179,7 +179,113 @@ class Engine:
         if self.folds is not None:
             self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
         if self.stage_cb is not None:
+            sr = getattr(self, "stage_ranges", None)
+            if sr:
+                self._zero_fresh_within(sr.get(name))
             self.stage_cb(name)
+
+    # ------------------------------------------------------------------ gradient zeroing (round 4)
+    # `optimizer.zero_grad()` + accumulate-into-zeros costs a 942-MB fill per step and a read of every weight gradient's old
+    # (zero) value by the pass that writes it.  Instead the FIRST weight-gradient write of a step into a range of the flat
+    # buffer STORES (`_gacc`): ranges that were written that way (learned from the steps themselves: `_gstore`) are left out of
+    # the step's zeroing, everything else - biases, norm parameters, embedding / position tables, conv kernels, alignment gaps,
+    # frozen tensors - is zeroed by ONE launch over a device table of (offset, count) rows (ops.zero_ranges).  A store range
+    # nobody wrote in a step (LayerDrop, a frozen layer) is zeroed when backward ends; after 8 such steps it leaves the store set.
+    # SMX_LAZY_ZERO=0: the plain fill.  Results are bit-identical either way (0 + x == x).
+    def begin_grads(self, zero=True, lazy=True):
+        st = self.st
+        self._gfresh = {}
+        self._gseen = set()
+        self._gzeroed = set()
+        if not zero:
+            return
+        if not lazy or os.environ.get("SMX_LAZY_ZERO") == "0" or st.grad.device.type != "cuda":
+            st.grad.zero_()
+            return
+        store = getattr(self, "_gstore", None)
+        if store is None:
+            store = self._gstore = {}            # offset -> [numel, consecutive steps without a write]
+            self._gplan = None
+        if self._gplan is None:
+            # complement of the store ranges in [0, total), cut into rows of <= 65536 elements
+            rows, pos = [], 0
+            for off in sorted(store):
+                if off > pos:
+                    rows.append((pos, off - pos))
+                pos = max(pos, off + store[off][0])
+            if pos < st.total:
+                rows.append((pos, st.total - pos))
+            tab = []
+            for a, n in rows:
+                for c in range(0, n, 65536):
+                    tab.append((a + c, min(65536, n - c)))
+            self._gplan = (torch.tensor(tab, dtype=torch.int64).to(self.dev) if tab else None, len(tab))
+        tab, n = self._gplan
+        if n:
+            ops.zero_ranges(st.grad, tab, n)
+        self._gfresh = {off: v[0] for off, v in store.items()}
+
+    def _gacc(self, out):
+        """-> True when a weight-gradient write into `out` must ADD to what is there, False when it is the step's first write
+        into a range the step did not zero (it then stores).  Also learns the ranges (see begin_grads)."""
+        fresh = getattr(self, "_gfresh", None)
+        if fresh is None or out.dtype != torch.float32:
+            return True
+        off = (out.data_ptr() - self.st.grad.data_ptr()) // 4
+        if not (0 <= off < self.st.total):
+            return True                           # not a slice of the flat gradient (conv kernels' tap-major scratch)
+        n = out.numel()
+        self._gseen.add(off)
+        if fresh.get(off) == n:
+            del fresh[off]
+            return False
+        store = getattr(self, "_gstore", None)
+        if store is None:
+            return True
+        known = store.get(off)
+        if known is not None and known[0] == n and off not in fresh:
+            return True                           # a later write of the step into a range its first write stored
+        # slow path (first steps, or a write that does not match what was learned): a still-unwritten store range under this
+        # write holds last step's values - zero it now and retire it; a range never seen before is learned for the next step
+        hit = [o for o, m in fresh.items() if o < off + n and off < o + m]
+        for o in hit:
+            self.st.grad[o:o + fresh[o]].zero_()
+            del fresh[o]
+            store.pop(o, None)
+            self._gplan = None
+        if not hit and not any(o < off + n and off < o + v[0] for o, v in store.items()):
+            store[off] = [n, 0]                   # zeroed this step (not in the plan yet); stores from the next step on
+            self._gplan = None
+        return True
+
+    def _zero_fresh_within(self, ranges):
+        """Zero the store ranges inside `ranges` [(a, b)] that nothing has written this step (a stage about to be reported
+        to the gradient reducer: a dropped layer must contribute zeros, not last step's gradient)."""
+        fresh = getattr(self, "_gfresh", None)
+        if not fresh or not ranges:
+            return
+        for off in [o for o, m in fresh.items() if any(a <= o and o + m <= b for a, b in ranges)]:
+            self.st.grad[off:off + fresh[off]].zero_()
+            self._gzeroed.add(off)
+            del fresh[off]
+
+    def end_grads(self):
+        """Store ranges without a write this step hold last step's values: zero them (dropped / frozen layers)."""
+        fresh, self._gfresh = getattr(self, "_gfresh", None), None
+        store = getattr(self, "_gstore", None)
+        if store is None:
+            return
+        for off, v in store.items():
+            if off in self._gseen:
+                v[1] = 0
+        for off, n in (fresh or {}).items():
+            self.st.grad[off:off + n].zero_()
+        for off in list(fresh or {}) + list(self._gzeroed):
+            if off in store:
+                store[off][1] += 1
+                if store[off][1] >= 8:
+                    del store[off]
+                    self._gplan = None
 
     # ------------------------------------------------------------------ buffers / parameter access
     def new(self, *shape, dt=None):
@@ -274,6 +380,8 @@ class Engine:
         ping-pong kernel with a split sized for one round of 256x256 items - timed on first use per shape (both write
         slabs, so the trial runs are side-effect free); the slab sum then lands in `out`."""
         n = No * Ko
+        if accumulate:
+            accumulate = self._gacc(out)
         cands = [(1, self._split(No, Ko, Kred))]
         if self.dt == BF16 and ops.pp_allowed() and cv is None and not getattr(self, "_side_active", False):
             sp = ops.pp_split(No, Ko, Kred)
@@ -333,13 +441,23 @@ class Engine:
         bv = xv if xv is not None else view(K)
         side = self._side if (side_ok and getattr(self, "_side_active", False)) else None
         grp = getattr(self, "_wg_group", None)
-        if (grp is not None and side is None and not kw and self.dt == BF16 and ops.pp_allowed() and M >= 4096 and len(grp) < 4
+        rows = getattr(self, "_wg_rows", None)           # LM stage: only problems over exactly this many rows are grouped
+        if (grp is not None and (side is None or rows is not None) and not kw and self.dt == BF16 and ops.pp_allowed()
+                and (M >= 4096 if rows is None else M == rows) and len(grp) < 8
                 and av.rows_per_batch <= 0 and bv.rows_per_batch <= 0 and not ((N | K | av.ld | bv.ld | av.off | bv.off) & 7)):
             # deferred: the layer's weight gradients go out as ONE grouped launch when the layer's backward ends (_wg_flush);
             # dy and x are never written again (every backward output is a fresh tensor, saved activations are read-only)
             grp.append((dy, x, gw, N, K, M, av, bv, alpha))
             if gb is not None:
-                ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
+                if side is not None:                     # (LM stage: the column sums stay on the second stream)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
+                    dy.record_stream(side)
+                else:
+                    ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
             return
         if side is None:
             self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
@@ -381,14 +499,20 @@ class Engine:
         torch.cuda.current_stream().wait_stream(self._wg_side)
         self._stage(stage)
 
-    def _wg_begin(self):
-        self._wg_group = [] if (_WGRAD_GROUP and self.dt == BF16) else None
+    def _wg_begin(self, rows=None):
+        """rows: group only the weight gradients over exactly `rows` rows, also while the LM stage's second stream is active
+        (round 4: a decoder layer's seven M = B x L weight gradients - 144 output tiles of 256 x 256, 16 K tiles deep - as one
+        launch on that stream instead of seven split-K launches + their slab reductions)."""
+        on = _WGRAD_GROUP and self.dt == BF16 and (rows is None or os.environ.get("SMX_LM_WGRAD_GROUP", "1") != "0")
+        self._wg_group = [] if on else None
+        self._wg_rows = rows if on else None
 
     def _wg_flush(self, side=None):
         """side: a HIP stream - the grouped launch (and its slab reduction) go there, behind everything the current stream has
         enqueued so far; the caller joins it before it reports the stage (speech_bwd: one layer later, so that the launch -
         216 work items on 256 CUs - runs beside the next layer's data-gradient chain, which takes the 40 CUs it leaves idle)."""
         grp, self._wg_group = getattr(self, "_wg_group", None), None
+        self._wg_rows = None
         if not grp:
             return False
         if side is not None and len(grp) > 1:
@@ -419,14 +543,15 @@ class Engine:
             per = (kst + want - 1) // want
             sp = (kst + per - 1) // per              # every K slice owns at least one K tile
             kw = dict(a_rc=True, b_rc=True, av=av, bv=bv, out_f32=True, alpha=alpha)
+            acc = self._gacc(gw)
             if sp > 1:
                 dst = slabs[off:off + sp * n]
                 kw.update(atomic=0, split_k=sp, split_stride=n)
-                outs.append((dst, sp, n, gw))
+                outs.append((dst, sp, n, gw, acc))
                 off += sp * n
             else:
                 dst = gw
-                kw.update(atomic=2)
+                kw.update(atomic=2 if acc else 0)
             probs.append((dy, x, dst, N, K, M, kw))
         mode = 8
         if ops.FR_MODE == "1":
@@ -444,8 +569,10 @@ class Engine:
                         ops.TUNE_LOG.append((key, None, ts[8], mode, None, None, ts[12]))
                 ops._tuned_set(key, mode)
         ops.gemm_group(probs, self.dt, mode=mode)
-        if outs:
-            ops.reduce_slabs_many([(dst, sp, n, gw) for dst, sp, n, gw in outs], accumulate=True)
+        for flag in (True, False):
+            sel = [(dst, sp, n, gw) for dst, sp, n, gw, acc in outs if acc == flag]
+            if sel:
+                ops.reduce_slabs_many(sel, accumulate=flag)
 
     def ln_fwd(self, x, wname, bname, M, D, eps, rms=False, act=ACT_NONE, pos=None, pos_period=0, pos_offset=0,
                want_sum=False, drop=None):
@@ -854,19 +981,32 @@ class Engine:
             else:
                 dprev = self.new(B * Tin, Cin)
                 prev_off, prev_bs = 0, Tin * Cin
+            # round 4 (SMX_CONV_DGRAD_KC=0: the rows-contiguous read of the forward's tap-major weight, rounds 1-3): the taps of
+            # each residue transposed once per step into a K-contiguous operand (ops.pack_conv_w_dgrad, 0.8 - 1.5 MB), so the
+            # data gradient is a forward-layout GEMM and runs on the 256-wide kernels
+            wd = None
+            if self.dt == BF16 and k >= s and os.environ.get("SMX_CONV_DGRAD_KC", "1") != "0":
+                wd = self.new(Co * Cin * k)
+                ops.pack_conv_w_dgrad(self.P(p + "conv.weight"), wd, Co, Cin, k, s, self.dt)
+            wd_off = 0
             for r in range(s):
                 taps = list(range(r, k, s))
                 nj = len(taps)
                 U = (Tin - 1 - r) // s + 1 if Tin - 1 - r >= 0 else 0
-                if U <= 0:
-                    continue
                 if nj == 0:          # stride > kernel: no feature extractor on the path has it (k >= s in every config)
                     raise NotImplementedError("conv layer with stride > kernel size")
+                wd_r, wd_off = (wd[wd_off:wd_off + Cin * nj * Co] if wd is not None else None), wd_off + Cin * nj * Co
+                if U <= 0:
+                    continue
                 av = view(Co, U, Tp * Co, (PAD - (nj - 1)) * Co)
-                bv = view(k * Cin, Co, -s * Cin, (r + (nj - 1) * s) * Cin)
                 cv = view(s * Cin, U, prev_bs, prev_off + r * Cin)
                 aux = sv["pre"][i - 1] if (i - 1 >= 1 and group) else None
                 ev = view(s * Cin, U, Tin * Cin, r * Cin) if aux is not None else None
+                if wd_r is not None:
+                    ops.gemm(dpre, wd_r, dprev, B * U, Cin, nj * Co, self.dt, av=av, cv=cv, ev=ev, aux_in=aux,
+                             act=ACT_GELU if aux is not None else ACT_NONE)
+                    continue
+                bv = view(k * Cin, Co, -s * Cin, (r + (nj - 1) * s) * Cin)
                 ops.gemm(dpre, sv["wp"][i], dprev, B * U, Cin, nj * Co, self.dt, b_rc=True, av=av, bv=bv, cv=cv, ev=ev,
                          aux_in=aux, act=ACT_GELU if aux is not None else ACT_NONE)
             if i - 1 >= 1 and not group:
@@ -1649,8 +1789,13 @@ class Engine:
                 dy = self.adapter_bwd(dy, sv["dec_layers"][i]["adapter"], lc.encoder_layers + i, Md, d)
             if uniform:
                 denc[2]["layer"] = i
+            side = self._side if getattr(self, "_side_active", False) else None
+            if side is not None:
+                self._wg_begin(rows=Md)
             dy = self.layer_bwd(dy, sv["dec_layers"][i], nm, pre_ln, act, rms=t5, denc=denc,
                                 dbias=tb["decoder"][1] if "decoder" in tb else None)
+            if side is not None:
+                self._wg_flush(side=side)
             denc[1] = False
         if "decoder" in tb:
             self._t5_bias_bwd(tb["decoder"], sv["t5_buckets"][1])
@@ -1867,11 +2012,11 @@ class Engine:
         sv = self.saved
         if sv is None or sv["dlogits"] is None:
             raise RuntimeError("backward() needs a forward() with labels")
-        if zero_grads:
-            self.st.grad.zero_()
+        self.begin_grads(zero=zero_grads)
         extra = sv.get("extra_denc")
         if extra is not None and gscale != 1.0:
             extra = extra * gscale
         de = self.lm_side_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
         self.speech_side_bwd(de, sv)
+        self.end_grads()
         self.saved = None

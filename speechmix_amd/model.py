@@ -364,10 +364,39 @@ class SpeechMixEED(nn.Module):
             self.store.rebind()
         return out
 
+    # Tied LM weights (shared embedding = encoder / decoder embed_tokens = lm_head = nlp_emb) appear under every one of their
+    # names in `state_dict()`, as in torch and in the reference's nn.Module classes.  `safetensors.save_file` - what
+    # transformers >= 4.4x's `Trainer._save` calls for a model that is not a `PreTrainedModel` - refuses tensors that share
+    # memory, and HF's own `save_pretrained` (the HF twins, ref:speechmix/hf_model.py) writes each tied weight once.  Setting
+    # `model.tied_aliases_in_state_dict = False` makes `state_dict()` do the same (one key per tied weight: the first name);
+    # `load_state_dict` fills the other names of a tied weight from whichever one a checkpoint holds, both ways.
+    tied_aliases_in_state_dict = True
+
+    def _tied_groups(self):
+        groups = {}
+        for name, p in self.named_parameters(remove_duplicate=False):
+            groups.setdefault(id(p), []).append(name)
+        return [g for g in groups.values() if len(g) > 1]
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if not self.tied_aliases_in_state_dict:
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            for g in self._tied_groups():
+                for alias in g[1:]:
+                    sd.pop(prefix + alias, None)
+        return sd
+
     def load_state_dict(self, state_dict, *a, **k):
         """Accepts this package's names, the HF twin's (ref:speechmix/hf_model.py - identical) and state dicts saved from
         ref:speechmix/model.py, whose speech encoder sits under `encoder_model.model.` with fairseq names (ref:eval.py:10)."""
-        out = super().load_state_dict(checkpoint.convert_speechmix_state_dict(state_dict), *a, **k)
+        state_dict = checkpoint.convert_speechmix_state_dict(state_dict)
+        for g in self._tied_groups():                     # a tied weight saved under one of its names loads under all
+            have = next((n for n in g if n in state_dict), None)
+            if have is not None:
+                for n in g:
+                    state_dict.setdefault(n, state_dict[have])
+        out = super().load_state_dict(state_dict, *a, **k)
         if self.store is not None:
             self.store.invalidate()
         return out
@@ -383,8 +412,8 @@ class SpeechMixEED(nn.Module):
         if self._zeroed_token == token:
             return
         self._zeroed_token = token
-        if not self._grads_live():
-            self.store.grad.zero_()
+        # (the split-node paths zero the whole buffer: their nodes run in autograd's order, not the engine's)
+        self.engine.begin_grads(zero=not self._grads_live(), lazy=False)
 
     # ------------------------------------------------------------------ reference hooks
     def custom_modules(self, **kwargs):
@@ -753,3 +782,37 @@ class SpeechMixSelf(SpeechMixEED):
                 if k in lo:
                     out[k + "_loss"] = lo[k].view(())
         return out
+
+
+# The HF-twin class names the reference's CLI dispatches on (`--HFSpeechMixEED` ..., ref:train.py:205-222; classes
+# ref:speechmix/hf_model.py:185, 450, 456, 505).  The twins differ from the s3prl-backed classes only in how the speech encoder is
+# loaded (an HF id / directory instead of an s3prl hub name) and in a wider forward signature; `speech_model_config` accepts both
+# kinds of names here, so they are the same classes - with the twins' extra forward keywords accepted.
+class _HFTwinForward:
+    def forward(self, input_values=None, decoder_text_prompt=None, text_input_ids=None, decoder_input_ids=None, labels=None,
+                encoder_outputs=None, decoder_outputs=None, past_key_values=None, use_cache=None, return_model_detail=False,
+                output_attentions=None, output_hidden_states=None, return_dict=None, attention_mask=None, **kwargs):
+        """ref:speechmix/hf_model.py:378-447.  `encoder_outputs` / `decoder_outputs` / `past_key_values` (the twins' generation
+        plumbing: a precomputed speech-encoder output, cached decoder states) have no counterpart in the fused step - decoding
+        is `generate()` here - and are refused rather than ignored."""
+        if encoder_outputs is not None or decoder_outputs is not None or past_key_values is not None:
+            raise NotImplementedError("encoder_outputs / decoder_outputs / past_key_values: use generate() (cached greedy decoding)")
+        return super().forward(input_values, input_text_prompt=decoder_text_prompt, decoder_input_ids=decoder_input_ids,
+                               labels=labels, return_model_detail=return_model_detail, text_input_ids=text_input_ids,
+                               attention_mask=attention_mask)
+
+
+class HFSpeechMixEED(_HFTwinForward, SpeechMixEED):
+    pass
+
+
+class HFSpeechMixFixed(_HFTwinForward, SpeechMixFixed):
+    pass
+
+
+class HFSpeechMixAdapter(_HFTwinForward, SpeechMixAdapter):
+    pass
+
+
+class HFSpeechMixSelf(_HFTwinForward, SpeechMixSelf):
+    pass

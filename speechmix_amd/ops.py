@@ -703,6 +703,11 @@ def pack_conv_w(w, out, Co, Ci, k, dtype):
             "smx_pack_conv_w")
 
 
+def pack_conv_w_dgrad(w, out, Co, Ci, k, stride, dtype):
+    L.check(L.lib().smx_pack_conv_w_dgrad(C.c_void_p(_ptr(w)), C.c_void_p(_ptr(out)), Co, Ci, k, stride, dtype, _stream()),
+            "smx_pack_conv_w_dgrad")
+
+
 def unpack_conv_dw(dwp, dw, Co, Ci, k):
     L.check(L.lib().smx_unpack_conv_dw(C.c_void_p(_ptr(dwp)), C.c_void_p(_ptr(dw)), Co, Ci, k, _stream()),
             "smx_unpack_conv_dw")
@@ -780,6 +785,11 @@ def cross_entropy(logits, labels, loss, argmax, dlogits, M, V, ldl, ldd, dtype, 
 def add(a, b, out, n, dtype):
     L.check(L.lib().smx_add(C.c_void_p(_ptr(a)), C.c_void_p(_ptr(b)), C.c_void_p(_ptr(out)), C.c_longlong(n), dtype,
                             _stream()), "smx_add")
+
+
+def zero_ranges(base, table, n):
+    """base[off : off + cnt] = 0 for the n (off, cnt) rows of the int64 device table (cnt <= 65536)."""
+    L.check(L.lib().smx_zero_ranges(C.c_void_p(_ptr(base)), C.c_void_p(_ptr(table)), n, _stream()), "smx_zero_ranges")
 
 
 def mask_rows(x, rows, nrows, emb, D, dtype):

@@ -109,6 +109,7 @@ class StepRunner:
                                                                  trainable=self.store.requires_grad),
                                    force_comm=self._force_comm)
         self.engine.stage_cb = self.reducer.stage_done
+        self.engine.stage_ranges = self.reducer.stages        # (ranges a reported stage hands to the reducer: Engine._stage)
 
     def current_lr(self):
         return float(self.lr(self.t)) if callable(self.lr) else float(self.lr)

@@ -74,9 +74,11 @@ def test_hip_fp32_matches_the_reference_at_full_dimensions(name):
 # bf16 (weights and every activation stored in bf16, fp32 accumulation) against the same fp32 reference outputs.  Bounds = 3 x the
 # error measured on the MI355X (profiles/r04_full_dimension_parity.txt), per case: (logits, loss, worst hidden state, worst
 # gradient relative to its tensor's largest entry, worst gradient L2 norm).
+# Measured (round 4): 1 x 10 s: logits 2.2e-2 (of a ~7 range), loss 1.4e-3 (of 10.9), hidden 5.7e-2 (of ~5), gradient entries 2.6e-2,
+# gradient norms 5.6e-3; 2 x 3 s: 2.2e-2 / 1.5e-3 / 6.3e-2 / 2.0e-2 / 5.6e-3.
 BF16_BOUNDS = {
-    "full_cfg2_1x10s": dict(logits=1.2e-1, loss=3e-3, hidden_worst=4e-1, grad_worst=1.5e-1, grad_norm_worst=5e-2),
-    "full_cfg2_2x3s": dict(logits=1.2e-1, loss=3e-3, hidden_worst=4e-1, grad_worst=1.5e-1, grad_norm_worst=5e-2),
+    "full_cfg2_1x10s": dict(logits=7e-2, loss=4.6e-3, hidden_worst=1.9e-1, grad_worst=7.7e-2, grad_norm_worst=1.7e-2),
+    "full_cfg2_2x3s": dict(logits=7e-2, loss=4.6e-3, hidden_worst=1.9e-1, grad_worst=7.7e-2, grad_norm_worst=1.7e-2),
 }
 
 

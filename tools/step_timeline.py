@@ -12,12 +12,11 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1),
                      int(r["Grid_Size_Z"]), r.get("Queue_Id", r.get("Stream_Id", "?"))))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if "sumsq" in r[2]]
-a, b = idx[step - 1] if step != 0 else 0, idx[step]
+# a step ends with the optimizer's last kernel: the last of a run of af_* (Adafactor) / opt_kernel launches
+is_opt = [("af_" in r[2] or "opt_kernel" in r[2] or "sumsq" in r[2]) for r in rows]
+idx = [i for i in range(len(rows)) if is_opt[i] and (i + 1 == len(rows) or not is_opt[i + 1])]
+a, b = idx[step - 1] if step != 0 else -1, idx[step]
 sel = rows[a + 1:b + 1]
-# the step starts after the previous optimizer's last kernel: skip its adafactor kernels
-while sel and ("af_" in sel[0][2] or "opt_kernel" in sel[0][2]):
-    sel = sel[1:]
 t0 = sel[0][0]
 busy_end, busy, gaps = t0, 0.0, 0.0
 out = []
@@ -40,7 +39,7 @@ if full:
         print(f"{t:10.1f} {d:8.1f} {g:6.1f} q{q} {gx:6d}x{gz:<3d} {n}")
 # coarse phases by marker kernels
 marks = [("conv0", "cnn fwd start"), ("group_pack", "posconv"), ("attn_fwd", "first attention"), ("ce_", "loss"),
-         ("attn_bwd", "first attention bwd"), ("conv0_bwd", "conv0 bwd"), ("sumsq", "optimizer")]
+         ("attn2_dq", "first attention bwd"), ("c0m_bwd", "conv0 bwd"), ("af_stats", "optimizer")]
 last = {}
 for t, d, g, q, gx, gz, n in out:
     for key, label in marks:
