@@ -290,10 +290,13 @@ def main():
         prof, oprof = ops.GemmProfile(), ops.OpProfile()
         ops.GEMM_PROFILE, ops.OP_PROFILE = prof, oprof
     if not args.no_profile:
+        if world > 1:
+            runner.reducer.profile = True          # events around the collectives (comm stream) and the final wait (compute stream)
         for _ in range(args.steps):
             runner.step(wave, labels)
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = ops.OP_PROFILE = None
+        runner.reducer.profile = False
         if world > 1:
             dist.barrier()
     final_loss = float(loss.item())
@@ -345,6 +348,22 @@ def main():
                 "final_loss": round(final_loss, 4)}
         if in_sync is not None:
             line["params_in_sync"] = in_sync
+        if world > 1:
+            # why it scales the way it does: how long the gradient collectives ran beside backward and how much of that was
+            # NOT hidden (compute stream waiting in GradReducer.finish), from the instrumented pass
+            cs = runner.reducer.comm_stats() if not args.no_profile else {}
+            secs = max(cs.get("allreduce_ms_per_step", 0.0), 1e-9) * 1e-3
+            line["comm"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "shared_gpu": bool(shared),
+                            "allreduce": cs.get("mode"), "bytes_reduced_per_step": round(cs.get("bytes_per_step", 0.0)),
+                            "collectives_per_step": round(cs.get("collectives_per_step", 0.0), 1),
+                            "allreduce_ms_per_step": round(cs.get("allreduce_ms_per_step", 0.0), 3),
+                            "exposed_ms_per_step": round(cs.get("exposed_ms_per_step", 0.0), 3),
+                            "lm_stage_allreduce_ms": round(cs.get("lm_stage_ms_per_step", 0.0), 3),
+                            "bus_GBps": round(2.0 * (world - 1) / world * cs.get("bytes_per_step", 0.0) / secs / 1e9, 1),
+                            "pp_backward_cus": ops.PP_BACKWARD_CUS,
+                            "note": "ring all-reduce bus bandwidth = 2 (n - 1) / n x bytes / time on the comm stream; exposed = compute "
+                                    "stream waiting for the comm stream after backward; a scaling curve needs > 1 GPU (the driver's "
+                                    "SCALE file): this builder's boxes have one"}
         if eval_ms is not None:
             line["eval_mode"] = {"ms_per_step": round(eval_ms, 3), "value": round(world * B * CLIP_SECONDS / (eval_ms * 1e-3), 1),
                                  "note": "p = 0: dropout / LayerDrop / SpecAugment off, all 12 encoder layers every step"}

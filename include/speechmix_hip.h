@@ -220,6 +220,8 @@ typedef struct SmxAfParams {
     long long racc_n, cacc_n; int ntensors, ntiles, nsegs;
     float lr, eps1, clip_threshold, grad_scale, max_grad_norm;
 } SmxAfParams;
+/* racc / cacc / cpart / usq_part / gsq_part are STORE-ONLY scratch (every element read was stored by exactly one tile of the same
+ * step): the caller need not zero them; no atomics anywhere in the step. */
 int smx_adafactor_step(const SmxAfParams* p, hipStream_t stream);
 
 /* Data-parallel gradient reduction: in-place sum-all-reduce of one contiguous bucket of the flat

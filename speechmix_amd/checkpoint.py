@@ -89,15 +89,20 @@ def read_state_file(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
+    import pickle
     try:
         sd = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as first:
+    except pickle.UnpicklingError as first:
+        # (only an unsupported global is retried: a truncated / unreadable file raises something else and is reported as such)
         # real fairseq .pt files keep an argparse.Namespace (`args`) next to the weights: allow exactly that class, nothing else
         import argparse
+        if not hasattr(torch.serialization, "safe_globals"):
+            raise RuntimeError(f"{path}: holds objects beyond tensors and this torch has no torch.serialization.safe_globals; "
+                               f"convert it first, e.g. torch.save({{'model': ckpt['model']}}, ...) in a trusted environment") from first
         try:
             with torch.serialization.safe_globals([argparse.Namespace]):
                 sd = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception:
+        except pickle.UnpicklingError:
             raise RuntimeError(f"{path}: not loadable with weights_only=True (objects beyond tensors / argparse.Namespace inside); "
                                f"convert it first, e.g. torch.save({{'model': ckpt['model']}}, ...) in a trusted environment") from first
     # where the weights sit: fairseq nests them under "model" (next to cfg / args / task_state), s3prl-converted upstream
@@ -105,8 +110,8 @@ def read_state_file(path: str) -> Dict[str, torch.Tensor]:
     # task_cfg / model_cfg), lightning-style files under "state_dict"
     for key in ("model", "model_weight", "state_dict"):
         if isinstance(sd, dict) and isinstance(sd.get(key), dict):
-            inner = sd[key]
-            if inner and all(torch.is_tensor(v) for v in inner.values()):
+            inner = {k: v for k, v in sd[key].items() if torch.is_tensor(v)}     # (fairseq keeps non-tensor entries such as `_ema` there)
+            if inner:
                 sd = inner
                 break
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}

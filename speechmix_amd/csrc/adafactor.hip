@@ -19,9 +19,11 @@
 // must end with identical parameters; with fp32 atomics summing the column partials of a matrix's row tiles and the per-tile
 // sum upd^2 in arrival order, two ranks drifted apart bit-wise within four steps (tests/test_gpu_r3.py, two ranks on one GPU).
 // Now a row tile stores its column partials into its own row of a scratch matrix [row tiles][C] that the fold sums in tile
-// order, a tile stores its sum upd^2 into its own slot and one thread per tensor adds the slots in tile order; the only
-// atomics left are the row sums of matrices wider than one column tile, which receive exactly two commutative additions
-// onto zero (the host plan refuses C > 2 * AF_MAXC).
+// order, a tile stores its sum upd^2 into its own slot and one thread per tensor adds the slots in tile order; the row sums of a
+// matrix wider than one column tile go the same way (every column tile stores its row sums into its own row of the scratch block
+// [column tiles][R] at rp_off, the fold adds them in tile order).  NO atomics are left in this file, and racc / cacc are
+// STORE-ONLY scratch: every element the fold reads was written by exactly one tile of the same step, so the host allocates them
+// uninitialised and nothing zeroes them - a change that adds into them (atomicAdd) would read garbage.
 #include "smx_common.h"
 
 struct SmxAfTensor {
@@ -51,7 +53,7 @@ struct SmxAfParams {
     const SmxAfSeg* segs;
     float* row;                   // factored state
     float* col;                   // factored column state; 1-D tensors keep their v here too
-    float* racc;                  // scratch, same layout as row / col / per tensor (zeroed by the launcher)
+    float* racc;                  // scratch, same layout as row / col / per tensor (store-only: never zeroed, see the header)
     float* cacc;
     float* rmean;                 // [nsegs]
     float* usq;                   // [ntensors] sum upd^2

@@ -107,6 +107,10 @@ class GradReducer:
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda and self.active else None
         self._done = set()
+        # profile=True (bench.py's instrumented pass): HIP events around every stage's collectives on the comm stream and around
+        # the compute stream's final wait -> comm_stats(): how long the reductions ran and how much of that backward did NOT hide
+        self.profile = False
+        self._ev, self._wait_ev, self._bytes, self._steps = [], [], 0, 0
         covered = sorted(r for rs in self.stages.values() for r in rs)
         for (a0, b0), (a1, b1) in zip(covered[:-1], covered[1:]):
             if b0 > a1:
@@ -126,8 +130,15 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
+                if self.profile:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 for a, b in self.stages[name]:
                     reduce_bucket(self.g[a:b], self.group)
+                if self.profile:
+                    e1.record()
+                    self._ev.append((name, e0, e1))
+                    self._bytes += 4 * sum(b - a for a, b in self.stages[name])
         else:
             for a, b in self.stages[name]:
                 reduce_bucket(self.g[a:b], self.group)
@@ -138,7 +149,28 @@ class GradReducer:
             if name not in self._done:
                 self.stage_done(name)
         if self.cuda and self.comm_stream is not None:
+            if self.profile:
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record()
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.profile:
+                w1.record()
+                self._wait_ev.append((w0, w1))
+                self._steps += 1
+
+    def comm_stats(self):
+        """After a device synchronize: per-step figures of the profiled steps - milliseconds the collectives ran on the comm
+        stream (sum over stages), milliseconds the compute stream stood waiting for them after backward (the EXPOSED part),
+        bytes reduced, collectives issued; per-stage milliseconds."""
+        n = max(self._steps, 1)
+        per_stage = {}
+        for name, e0, e1 in self._ev:
+            per_stage[name] = per_stage.get(name, 0.0) + e0.elapsed_time(e1)
+        total = sum(per_stage.values())
+        return dict(steps=self._steps, allreduce_ms_per_step=total / n,
+                    exposed_ms_per_step=sum(w0.elapsed_time(w1) for w0, w1 in self._wait_ev) / n,
+                    bytes_per_step=self._bytes / n, collectives_per_step=len(self._ev) / n,
+                    lm_stage_ms_per_step=per_stage.get("lm", 0.0) / n, mode=ALLREDUCE_MODE)
 
 
 def shard_batch(n_items: int, rank: int, world: int):

@@ -39,7 +39,9 @@ class HFHostRNG:
     (TF:models/wav2vec2/modeling_wav2vec2.py:139 `np.random.rand(1)`, :183 `np.random.choice`) and torch's CPU generator for
     LayerDrop (TF:...wav2vec2.py:712 `torch.rand([])`).  With no arguments the PROCESS-GLOBAL streams are used, so
     `np.random.seed(k)` / `torch.manual_seed(k)` reproduce HF's indices and keep decisions bit for bit
-    (tests/test_host_logic_r3.py); `HFHostRNG.seeded(k)` owns private streams with the same draw order."""
+    (tests/test_train_mode_r3.py); `HFHostRNG.seeded(k)` owns private streams with the same draw order
+    (`StepRunner(..., seed=k)` installs one).  HF draws LayerDrop in train mode only in effect (`training and rand < p`
+    short-circuits here exactly as `self.training and ...` does there), so an eval pass consumes nothing from either stream."""
 
     def __init__(self, np_state=None, torch_gen=None):
         self.np, self.tg = np_state, torch_gen
@@ -64,10 +66,17 @@ class HFHostRNG:
 class RecordedHostRNG:
     """Plays back recorded decisions (fixtures): `mask` = boolean [B, T] SpecAugment mask or None, `keep` = per-layer booleans."""
 
-    def __init__(self, mask=None, keep=None):
+    def __init__(self, mask=None, keep=None, fallback=None):
         self.mask = None if mask is None else np.asarray(mask, dtype=bool)
         self.keep = None if keep is None else [bool(k) for k in keep]
         self._i = 0
+        self.fallback = fallback or HFHostRNG()          # a keep-only recording with mask_time_prob > 0 still draws its spans
+
+    def rand(self):
+        return self.fallback.rand()
+
+    def choice(self, n, k):
+        return self.fallback.choice(n, k)
 
     def layerdrop(self):                       # < layerdrop <=> dropped
         if self.keep is None:
@@ -1565,9 +1574,14 @@ class Engine:
                        nxt=torch.empty(B, dtype=torch.int64, device=self.dev), done=torch.zeros(B, dtype=torch.bool, device=self.dev),
                        out=torch.empty(B, Lmax, dtype=torch.int64, device=self.dev), lse=self.new(B * H, dt=torch.float32),
                        pbias=torch.empty(H, Lmax, Lmax, dtype=torch.float32, device=self.dev) if t5 else None,
-                       fin=torch.empty((), dtype=torch.int64, device=self.dev), graphs={}, calls=0, pool=None)
+                       fin=torch.empty((), dtype=torch.int64, device=self.dev), graphs={}, calls=0, pool=None, eager_done=set(),
+                       failures=0)
+            stt["bytes"] = sum(t.numel() * t.element_size() for t in stt["xkv"] + stt["cache"] + [stt["logits"]])
             if use_graphs:
-                if len(dc) >= 4:                      # a handful of configurations at most (each holds its captured steps)
+                # a handful of configurations at most, and no more than 4 GB of static state (each holds its K/V caches, the
+                # cross-attention K/V and its captured steps); S - the LM-encoder length - is part of the key, so variable-length
+                # evaluation mostly runs eagerly and the oldest entries make room
+                while dc and (len(dc) >= 4 or sum(v["bytes"] for v in dc.values()) + stt["bytes"] > (4 << 30)):
                     dc.pop(next(iter(dc)))
                 dc[key] = stt
         xkv, cache, logits, tok, nxt, done, out, lse, pbias, fin = (stt[k] for k in ("xkv", "cache", "logits", "tok", "nxt", "done",
@@ -1654,7 +1668,12 @@ class Engine:
         stt["calls"] += 1
         steps = 0
         for t in range(Lmax):
-            if replay:
+            if replay and t not in stt["eager_done"] and t not in stt["graphs"]:
+                # a step is captured only after it has run eagerly once (a first call that stopped early at eos leaves its later
+                # steps' GEMM shapes untuned, and the tuner's synchronize is illegal inside a capture)
+                step(t)
+                stt["eager_done"].add(t)
+            elif replay:
                 g = stt["graphs"].get(t)
                 if g is None:
                     g = torch.cuda.CUDAGraph()
@@ -1665,7 +1684,9 @@ class Engine:
                         import warnings
                         warnings.warn(f"greedy_decode: HIP graph capture failed ({e}); decoding eagerly")
                         stt["graphs"].clear()
-                        stt["calls"] = -(1 << 30)      # never try again for this configuration
+                        stt["failures"] += 1
+                        # one retry (from the next call on, after this call's eager pass); a second failure disables replay
+                        stt["calls"] = 1 if stt["failures"] < 2 else -(1 << 30)
                         replay = False
                         step(t)
                         steps += 1
@@ -1678,6 +1699,8 @@ class Engine:
                 g.replay()
             else:
                 step(t)
+                if use_graphs:
+                    stt["eager_done"].add(t)
             steps += 1
             if keep_logits is not None:
                 keep_logits.append(logits[:, :V].clone())

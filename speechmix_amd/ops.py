@@ -185,9 +185,29 @@ def _fr_applicable(p, dtype):
     return True
 
 
+# SMX_GEMM_BYTES_LOG=path: the ALGORITHMIC bytes (_gemm_bytes) of every bf16 GEMM launch of the process, in launch order, written
+# as a JSON list at exit.  Every smx_gemm / smx_gemm_group call dispatches exactly one `gemm_bf16_*` kernel, so the list lines up
+# with the dispatch order of a rocprofv3 counter pass of the same command: tools/pmc_traffic.py puts the two side by side per
+# kernel instantiation (measured HBM traffic / algorithmic bytes = the waste ratio).
+_BYTES_LOG_PATH = os.environ.get("SMX_GEMM_BYTES_LOG", "")
+_BYTES_LOG = [] if _BYTES_LOG_PATH else None
+
+
+def _bytes_log_save():
+    if _BYTES_LOG is not None:
+        import json
+        with open(_BYTES_LOG_PATH, "w") as f:
+            json.dump(_BYTES_LOG, f)
+
+
+_atexit.register(_bytes_log_save)
+
+
 def _launch(p, dtype):
     if (p.tr_mode & 255) in (8, 12, 13) and pp_cus():
         p.tr_mode = (p.tr_mode & 0xffff) | (pp_cus() << 16)          # persistent grid cap (gemm_pp.hip)
+    if _BYTES_LOG is not None and dtype == BF16:
+        _BYTES_LOG.append(_gemm_bytes(p, dtype))
     L.check(L.lib().smx_gemm(C.byref(p), dtype, _stream()), "smx_gemm")
 
 
@@ -923,11 +943,11 @@ class AdafactorPlan:
         self._b2_ev = [None] * 4
         self._b2_i = 0
 
-    def step(self, p, g, shadow, gnorm_sq, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
+    def step(self, p, g, shadow, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
              max_grad_norm=0.0):
         """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched).
         max_grad_norm > 0: global-norm clipping (HF Trainer's clip_grad_norm_ before optimizer.step); the norm comes out of the
-        step's own statistics pass over the gradient (`gnorm_sq` is accepted for the older calling convention and ignored)."""
+        step's own statistics pass over the gradient."""
         np = self._np
         act = np.ones(self.n, dtype=bool) if active is None else np.asarray(active, dtype=bool)
         self.steps[act] += 1
@@ -984,6 +1004,8 @@ def gemm_group(problems, dtype, mode=8):
         e0, e1 = prof.events()
         e0.record()
     arr[0].tr_mode = mode | (pp_cus() << 16)          # mode 12: free-running schedule; bits 16..: persistent grid cap
+    if _BYTES_LOG is not None and dtype == BF16:
+        _BYTES_LOG.append(nbytes)
     L.check(L.lib().smx_gemm_group(arr, len(problems), dtype, _stream()), "smx_gemm_group")
     if prof is not None:
         e1.record()

@@ -47,18 +47,27 @@ def linear_schedule_with_warmup(lr, warmup_steps, total_steps):
 
 class StepRunner:
     def __init__(self, model, lr=4e-5, optimizer="adamw", betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_grad_norm=1.0, momentum=0.0, force_comm=False, grad_accum=1, sync_params=True):
+                 max_grad_norm=1.0, momentum=0.0, force_comm=False, grad_accum=1, sync_params=True, seed=None):
         """lr: a float, or a callable step -> lr (`linear_schedule_with_warmup`).
         grad_accum: micro-batches per optimizer step (the reference trains with HF Trainer's
         gradient_accumulation_steps, ref:train.py:159, 295: every micro-batch's loss is divided by it, gradients add up, and
         the all-reduce / clip / optimizer update run on the last one).
         sync_params: with more than one rank, broadcast rank 0's parameters at construction (DDP does the same), so that
-        ranks cannot start from different weights."""
+        ranks cannot start from different weights.
+        seed: private, reproducible host streams for this runner's model - SpecAugment spans and LayerDrop draws from
+        `HFHostRNG.seeded(seed)` (HF's draw order; HF's Trainer seeds every rank alike, so the same seed on every rank), dropout
+        mask seeds from `seed` and the rank.  None: the process-global np.random / torch streams, as HF uses them."""
         model._need_engine()
         self.grad_accum = max(1, int(grad_accum))
         self._micro = 0
         self._dropped_all = set()
         self.model, self.store, self.engine = model, model.store, model.engine
+        if seed is not None:
+            import numpy as _np
+            from .engine import HFHostRNG
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            self.engine.host_rng = HFHostRNG.seeded(seed)
+            self.engine.drop_rng = _np.random.default_rng([int(seed), rank])
         self.kind = optimizer
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm, self.momentum = lr, betas, eps, weight_decay, \
             max_grad_norm, momentum
@@ -160,7 +169,7 @@ class StepRunner:
         dropped = self._dropped_all if self.world == 1 else set()
         if self.af is not None:
             active = [f and (l not in dropped) for f, l in zip((st.requires_grad(nm) for nm in self.af_names), self._af_layer)]
-            self.af.step(st.master, st.grad, sh, self.gnorm_sq if clip > 0 else None, lr, active=active,
+            self.af.step(st.master, st.grad, sh, lr, active=active,
                          grad_scale=inv_world, max_grad_norm=clip)
             st.mark_shadow_fresh()
             return out["loss"]

@@ -66,7 +66,7 @@ def test_large_configs_full_size_properties(cfg):
     # bf16 storage makes every activation a step function of its fp32 value: a different fp32 summation order (another K
     # split at another batch size) flips a few roundings by one ulp in the first conv GEMM (478 of 2.4 M elements measured),
     # and every later GEMM sums ~1 500 such inputs, so the flips spread: 37 % of the CNN's outputs differ by one ulp between a
-    # 1-clip and an 8-clip batch, 1.6 % of the hidden states' range after the encoder (tools/gpu_clip_indep2.py).  The fp32
+    # 1-clip and an 8-clip batch, 1.6 % of the hidden states' range after the encoder (measured round 2).  The fp32
     # path is bit-identical across batch sizes (tests/test_gpu_fullsize_parity.py).  Measured here: rel 6.1e-2 / cos 0.9984
     # (config 4), bounds = 3x.
     assert rel < 0.18 and cos > 0.985, (rel, cos)

@@ -89,7 +89,7 @@ def test_adafactor_flat_step_matches_oracle():
         gd = g.to(dev)
         ops.sumsq(gd, total, gnorm)
         clip = min(1.0, 1.0 / (g.norm().item() * 0.5 + 1e-6))
-        plan.step(pd, gd, shadow, gnorm, 5e-4, active=active, grad_scale=0.5, max_grad_norm=1.0)
+        plan.step(pd, gd, shadow, 5e-4, active=active, grad_scale=0.5, max_grad_norm=1.0)
         for i, (o, s) in enumerate(zip(offs, shapes)):
             if active[i]:
                 O.adafactor_step(ref[i], g[o:o + torch.Size(s).numel()].view(s) * (0.5 * clip), states[i], lr=5e-4)

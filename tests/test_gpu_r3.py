@@ -268,8 +268,8 @@ def test_two_ranks_share_one_gpu_over_gloo_through_the_whole_step():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SMX_BENCH_SHARED_GPU="1", SMX_BENCH_CHECK_SYNC="1")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "4",
-                        "--no-cpu-baseline", "--no-profile", "--no-eval-leg", "--seed", "3"],
-                       env=env, capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline", "--no-eval-leg", "--seed", "3"],
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -277,6 +277,12 @@ def test_two_ranks_share_one_gpu_over_gloo_through_the_whole_step():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
     assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 50
     assert d.get("params_in_sync") is True, d
+    # round 4: the line says what the collectives cost and how much of it backward did not hide (instrumented pass)
+    c = d["comm"]
+    assert c["ranks"] == 2 and c["backend"] == "gloo" and c["shared_gpu"] is True
+    assert 0.9e9 < c["bytes_reduced_per_step"] < 1.0e9           # every trainable fp32 gradient of config 2 once: 942 MB
+    assert c["collectives_per_step"] >= 14 and c["allreduce_ms_per_step"] > 0 and c["exposed_ms_per_step"] >= 0
+    assert c["exposed_ms_per_step"] <= c["allreduce_ms_per_step"] + 1.0
 
 
 @pytest.mark.gpu

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 profile artefacts, one gpurun call:   gpurun --timeout 2400 -- bash tools/run_profiles_r3.sh
-# Writes under gpurun_out/r3prof/ ; the summaries are copied to profiles/r03_* by hand after the run.
+# Round-4 profile artefacts, one gpurun call:   gpurun --timeout 2400 -- bash tools/run_profiles_r4.sh
+# Writes under gpurun_out/r4prof/ ; the summaries are copied to profiles/r04_* by hand after the run.
 # (rocprofv3: the program itself after `--`, never a wrapper; PMC passes are separate runs with --kernel-trace only.)
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/r3prof
+O=gpurun_out/r4prof
 mkdir -p $O
 export TMPDIR=/tmp SMX_TUNE_FILE=$PWD/$O/tune.json
 # 1. the bench line (also fills the tuner file so that every later pass launches the same kernels)
@@ -18,13 +18,15 @@ S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$S" ] && cp "$S" $O/kernel_stats.csv
 # 3. PMC passes (short run: 2 warm-up + 2 steps)
 ARGS="bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-profile --no-eval-leg"
+export SMX_GEMM_BYTES_LOG=$PWD/$O/gemm_bytes_log.json      # (algorithmic bytes of every GEMM launch of the FETCH pass, in launch order)
 timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o p -- python3 $ARGS > $O/pmc_fetch.log 2>&1
+unset SMX_GEMM_BYTES_LOG
 timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o p -- python3 $ARGS > $O/pmc_write.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/pmc_sq -o p -- python3 $ARGS > $O/pmc_sq.log 2>&1
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 Q=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1)
-[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic.py "$F" "$W" > $O/pmc.json 2> $O/pmc.err
+[ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic.py "$F" "$W" $O/gemm_bytes_log.json > $O/pmc.json 2> $O/pmc.err
 [ -n "$Q" ] && python3 tools/pmc_mfma.py "$Q" > $O/pmc_mfma.json 2> $O/pmc_mfma.err
 # the raw traces are large: keep the summaries only
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq
