@@ -117,6 +117,15 @@ int smx_conv0_bwd(const SmxConv0Params* p, int dtype, hipStream_t stream);
 
 /* positional conv helpers (group-major pack, weight_norm forward/backward). TF:...wav2vec2.py:326-379 */
 int smx_group_pack(const void* x, void* xg, int B, int T, int C, int G, int K, int pad_front, int dtype, hipStream_t stream);
+/* Time-blocked form of the same convolution (round 4; csrc/posconv.hip): J consecutive frames per GEMM row give N = J * Cg outputs.
+ * smx_posconv_pack_w: the J-times shifted taps [G][J * Cg][(K + J - 1) * Cg] from smx_wn_fwd's forward pack (flip = 1: the
+ * data-gradient operand); smx_posconv_unpack: the GEMM's group-major fp32 output [G][B][Tq][Cg] -> token-major [B * T][C] with
+ * bias / pre-activation copy / activation / residual; smx_posconv_fold_dw: the blocked weight gradient's J shifted diagonals
+ * summed into the forward-pack layout [G][Cg][K * Cg] that smx_wn_bwd takes. */
+int smx_posconv_pack_w(const void* wp, void* out, int G, int Cg, int K, int J, int flip, int dtype, hipStream_t stream);
+int smx_posconv_unpack(const float* tmp, const float* bias, const void* resid, void* pre, void* y, int B, int T, int C, int G,
+                       int Tq, int act, int dtype, hipStream_t stream);
+int smx_posconv_fold_dw(const float* dwJ, float* dwp, int G, int Cg, int K, int J, hipStream_t stream);
 /* norm and scratch_s: K * (1 + smx_wn_partial_blocks(C, Cg)) floats each (results in the first K; K <= 256) */
 int smx_wn_partial_blocks(int C, int Cg);
 int smx_wn_fwd(const float* v, const float* g, void* wp, void* wf, float* norm, int C, int Cg, int K, int dtype, hipStream_t stream);

@@ -135,3 +135,135 @@ extern "C" int smx_wn_bwd(const float* dwp, const float* v, const float* g, cons
     hipLaunchKernelGGL(wn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, stream, dwp, v, g, norm, scratch_s, dg, dv, C, Cg, K);
     SMX_CHECK_LAUNCH();
 }
+
+
+// ---------------------------------------------------------------- time-blocked positional convolution (round 4)
+// As a batched GEMM the grouped conv has N = Cg = 48 outputs per group: 62 % of a 128-wide tile (and all of a 256-wide one beyond
+// column 48) multiplies nothing.  Blocking J consecutive frames into ONE GEMM row - row (b, t') = frames J t' .. J t' + J - 1 of
+// clip b, A = the (K + J - 1) Cg inputs they see together (one contiguous run of the group-major padded layout, rows J Cg apart),
+// B = the taps shifted J times - gives N = J Cg outputs at (K + J - 1) / K of the flops, and the output [G][B][J T'][Cg] is again the
+// group-major layout.  J = 4: N = 192, K' = 6288; forward 295 -> 150 us, data gradient 447 -> 150 us, weight gradient 475 -> 300 us
+// at config 2 (tools/gpu_posconv_probe.py).
+//
+//   smx_posconv_pack_w:   out[g][(j, a)][(kk, b)] = 0 <= kk - j < K ? (flip ? wp[g][b][K - 1 - (kk - j)][a] : wp[g][a][kk - j][b]) : 0
+//                         (wp = smx_wn_fwd's forward pack [G][co][k Cg + ci]; flip = 1: the data-gradient operand, taps reversed and
+//                         the roles of ci / co swapped)
+//   smx_posconv_unpack:   group-major fp32 [G][B][Tq][Cg] -> token-major [B T][C] with the epilogue the fused GEMM had:
+//                         v = tmp + bias; pre = v; y = act(v) + resid      (data gradient: y = tmp + resid)
+//   smx_posconv_fold_dw:  dwp[g][co][k][ci] = sum_j dwJ[g][(j, co)][(k + j)][ci]     (the J shifted diagonals of the blocked gradient)
+template <typename T>
+__global__ void posconv_pack_w_kernel(const T* __restrict__ wp, T* __restrict__ out, int G, int Cg, int K, int J, int flip) {
+    const int Kp = K + J - 1;
+    const long long n = (long long)G * J * Cg * Kp * Cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = i % Cg;
+        const int kk = (i / Cg) % Kp;
+        const int a = (i / ((long long)Cg * Kp)) % Cg;
+        const int j = (i / ((long long)Cg * Kp * Cg)) % J;
+        const int g = i / ((long long)Cg * Kp * Cg * J);
+        const int k = kk - j;
+        T v = T(0);
+        if (k >= 0 && k < K)
+            v = flip ? wp[(((long long)g * Cg + b) * K + (K - 1 - k)) * Cg + a] : wp[(((long long)g * Cg + a) * K + k) * Cg + b];
+        out[i] = v;
+    }
+}
+// flip = 0 fast path: output row (g, j, a) = [j Cg zeros][row (g, a) of the source: K Cg contiguous elements][(J - 1 - j) Cg zeros]
+// - a shifted row copy, 16 B per thread.  (The data-gradient operand is the same copy of smx_wn_fwd's flipped pack `wf`.)
+template <typename T>
+__global__ void posconv_shift_rows_kernel(const T* __restrict__ src, T* __restrict__ out, int rows, int Cg, int K, int J) {
+    const int Kp = K + J - 1, cv = Kp * Cg / 8, kv = K * Cg / 8;
+    const long long n = (long long)rows * J * cv;                 // rows = G * Cg source rows
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv);
+        const long long rj = i / cv;                              // = (g * J + j) * Cg + a
+        const int a = (int)(rj % Cg), j = (int)((rj / Cg) % J);
+        const long long g = rj / ((long long)Cg * J);
+        const int sc = c - j * (Cg / 8);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (sc >= 0 && sc < kv) load8(src + (g * Cg + a) * (long long)K * Cg + sc * 8, v);
+        store8(out + i * 8, v);
+    }
+}
+extern "C" int smx_posconv_pack_w(const void* wp, void* out, int G, int Cg, int K, int J, int flip, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!wp || !out || G <= 0 || Cg <= 0 || K <= 0 || J <= 0) return SMX_EINVAL;
+    const long long n = (long long)G * J * Cg * (K + J - 1) * Cg;
+    if (!flip && !(Cg & 7)) {
+        const long long nv = n / 8;
+        int blocks = (int)((nv + 255) / 256 > 8192 ? 8192 : (nv + 255) / 256);
+        if (dtype == SMX_BF16) hipLaunchKernelGGL(posconv_shift_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)wp, (bf16_t*)out, G * Cg, Cg, K, J);
+        else if (dtype == SMX_F32) hipLaunchKernelGGL(posconv_shift_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)wp, (float*)out, G * Cg, Cg, K, J);
+        else return SMX_EINVAL;
+        SMX_CHECK_LAUNCH();
+    }
+    int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(posconv_pack_w_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)wp, (bf16_t*)out, G, Cg, K, J, flip);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(posconv_pack_w_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)wp, (float*)out, G, Cg, K, J, flip);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+template <typename T>
+__global__ void posconv_unpack_kernel(const float* __restrict__ tmp, const float* __restrict__ bias, const T* __restrict__ resid,
+                                      T* __restrict__ pre, T* __restrict__ y, int B, int Tt, int C, int G, int Tq, int act) {
+    const int Cg = C / G, cv = C / 8;
+    const long long n = (long long)B * Tt * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (i % cv) * 8;
+        const int t = (i / cv) % Tt;
+        const int b = i / ((long long)cv * Tt);
+        const int g = c / Cg, co = c % Cg;
+        const float* src = tmp + (((long long)g * B + b) * Tq + t) * Cg + co;
+        float v[8], r[8];
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[c + e];
+        }
+        const long long o = ((long long)b * Tt + t) * C + c;
+        if (pre) store8(pre + o, v);
+        if (act != SMX_ACT_NONE) act_fwd8(v, act);
+        if (resid) {
+            load8(resid + o, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        store8(y + o, v);
+    }
+}
+extern "C" int smx_posconv_unpack(const float* tmp, const float* bias, const void* resid, void* pre, void* y, int B, int T, int C, int G,
+                                  int Tq, int act, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!tmp || !y || C % G || (C / G) % 8 || Tq < T) return SMX_EINVAL;
+    const long long n = (long long)B * T * (C / 8);
+    int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(posconv_unpack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, tmp, bias, (const bf16_t*)resid, (bf16_t*)pre, (bf16_t*)y, B, T, C, G, Tq, act);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(posconv_unpack_kernel<float>, dim3(blocks), dim3(256), 0, stream, tmp, bias, (const float*)resid, (float*)pre, (float*)y, B, T, C, G, Tq, act);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+__global__ void posconv_fold_dw_kernel(const float* __restrict__ dwJ, float* __restrict__ dwp, int G, int Cg, int K, int J) {
+    const int Kp = K + J - 1;
+    const long long n = (long long)G * Cg * K * Cg;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = i % Cg;
+        const int k = (i / Cg) % K;
+        const int co = (i / ((long long)Cg * K)) % Cg;
+        const int g = i / ((long long)Cg * K * Cg);
+        float s = 0.f;
+        for (int j = 0; j < J; ++j)                              // (fixed order: deterministic)
+            s += dwJ[((((long long)g * J + j) * Cg + co) * Kp + (k + j)) * Cg + ci];
+        dwp[i] = s;
+    }
+}
+extern "C" int smx_posconv_fold_dw(const float* dwJ, float* dwp, int G, int Cg, int K, int J, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!dwJ || !dwp || G <= 0 || Cg <= 0 || K <= 0 || J <= 0) return SMX_EINVAL;
+    const long long n = (long long)G * Cg * K * Cg;
+    int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(posconv_fold_dw_kernel, dim3(blocks), dim3(256), 0, stream, dwJ, dwp, G, Cg, K, J);
+    SMX_CHECK_LAUNCH();
+}

@@ -1042,6 +1042,13 @@ class Engine:
                           None, None, self.dt)
 
     # ------------------------------------------------------------------ positional conv embedding
+    def _posconv_J(self):
+        """Frames per GEMM row of the time-blocked positional conv (csrc/posconv.hip; SMX_POSCONV_J=1: the plain N = Cg form)."""
+        if self.dt != BF16 and os.environ.get("SMX_POSCONV_J_F32") != "1":      # (fp32 parity path: the plain form; =1: tests of the blocked one)
+            return 1
+        J = int(os.environ.get("SMX_POSCONV_J", "4"))
+        return J if J > 1 and (J * (self.ec.hidden_size // self.ec.num_conv_pos_embedding_groups)) % 8 == 0 else 1
+
     def posconv_fwd(self, h, B, T):
         ec, ep = self.ec, self.ep
         d, K, G = ec.hidden_size, ec.num_conv_pos_embeddings, ec.num_conv_pos_embedding_groups
@@ -1049,16 +1056,35 @@ class Engine:
         pre_n = f"{ep}encoder.pos_conv_embed.conv."
         wp = self.new(G * Cg * K * Cg)
         norm = self.new(ops.wn_scratch_floats(d, Cg, K), dt=torch.float32)        # [K] norms, then reduction scratch
+        J = self._posconv_J()
+        # (time-blocked form: the flipped data-gradient pack [G][ci][k' Cg + co] is emitted here too - its blocked operand is then the
+        # same shifted row copy as the forward's)
+        wf = self.new(G * Cg * K * Cg) if J > 1 else None
         ops.wn_fwd(self.P(pre_n + "parametrizations.weight.original1"), self.P(pre_n + "parametrizations.weight.original0"),
-                   wp, None, norm, d, Cg, K, self.dt)
-        xg = self.new(G * B * Tp * Cg)
-        ops.group_pack(h, xg, B, T, d, G, K, P, self.dt)
+                   wp, wf, norm, d, Cg, K, self.dt)
         s = self.new(B * T, d)
         pre = self.new(B * T, d)
+        if J > 1:
+            # time-blocked: row (b, t') = frames J t' .. J t' + J - 1, N = J Cg outputs, K' = (K + J - 1) Cg inputs; the fp32 output is
+            # the group-major layout [G][B][Tq][Cg], unpacked with the epilogue the fused GEMM had (same fp32 arithmetic)
+            Tb = (T + J - 1) // J
+            Tq, Kp = J * Tb, (K + J - 1) * Cg
+            Tp2 = Tq + K - 1
+            wJ = self.new(G * J * Cg * Kp)
+            ops.posconv_pack_w(wp, wJ, G, Cg, K, J, False, self.dt)
+            xg = self.new(G * B * Tp2 * Cg)
+            ops.group_pack(h, xg, B, T, d, G, K + (Tq - T), P, self.dt)
+            tmp = self.new(G * B * Tq * Cg, dt=torch.float32)
+            ops.gemm(xg, wJ, tmp, B * Tb, J * Cg, Kp, self.dt, av=view(J * Cg, Tb, Tp2 * Cg), bv=view(Kp), cv=view(J * Cg), out_f32=True,
+                     nbatch=G, batch_a=B * Tp2 * Cg, batch_b=J * Cg * Kp, batch_c=B * Tq * Cg)
+            ops.posconv_unpack(tmp, self.P(pre_n + "bias"), h, pre, s, B, T, d, G, Tq, ACT_GELU, self.dt)
+            return s, dict(xg=xg, wp=wp, wf=wf, norm=norm, pre=pre, B=B, T=T, J=J)
+        xg = self.new(G * B * Tp * Cg)
+        ops.group_pack(h, xg, B, T, d, G, K, P, self.dt)
         ops.gemm(xg, wp, s, B * T, Cg, K * Cg, self.dt, av=view(Cg, T, Tp * Cg), bv=view(K * Cg), cv=view(d),
                  bias=self.P(pre_n + "bias"), resid=h, aux_out=pre, act=ACT_GELU, nbatch=G, batch_a=B * Tp * Cg,
                  batch_b=Cg * K * Cg, batch_c=Cg, batch_bias=Cg)
-        return s, dict(xg=xg, wp=wp, norm=norm, pre=pre, B=B, T=T)
+        return s, dict(xg=xg, wp=wp, norm=norm, pre=pre, B=B, T=T, J=1)
 
     def posconv_bwd(self, ds, sv):
         ec, ep = self.ec, self.ep
@@ -1069,9 +1095,57 @@ class Engine:
         dpre = self.new(B * T, d)
         ops.act_bwd(ds, sv["pre"], dpre, B * T, d, view(d), ACT_GELU, self.dt)
         v_n, g_n = pre_n + "parametrizations.weight.original1", pre_n + "parametrizations.weight.original0"
-        if self.tr(v_n, g_n, pre_n + "bias"):
+        J = sv.get("J", 1)
+        train = self.tr(v_n, g_n, pre_n + "bias")
+        if train:
             ops.colsum(dpre, self.G(pre_n + "bias"), B * T, d, d, self.dt, folds=self.folds)
-            n = G * Cg * K * Cg
+        n = G * Cg * K * Cg
+        if J > 1:
+            Tb = (T + J - 1) // J
+            Tq, Kp = J * Tb, (K + J - 1) * Cg
+            Tp2 = Tq + K - 1
+            dyg = self.new(G * B * Tp2 * Cg)               # d pre, group-major, K - 1 - P zero frames in front: both gradients read it
+            ops.group_pack(dpre, dyg, B, T, d, G, K + (Tq - T), K - 1 - P, self.dt)
+            if train:
+                # blocked weight gradient [G][J Cg][K'] = dY^T X over the B Tb rows (frame j of row t' sits K - 1 - P + J t' + j frames
+                # into dyg), then its J shifted diagonals folded into the forward-pack layout
+                nJ = J * Cg * Kp
+                cands = [(1, 1), (1, 2), (1, 4), (8, 1), (8, 2)]
+                key = ("posconv_wgrad", self.dt, B, T, G, Cg, K, J)
+                pick = ops._tuned_get(key)
+                if isinstance(pick, list):
+                    pick = tuple(pick)
+
+                def run(mode, split, out):
+                    ops.gemm(dyg, sv["xg"], out, J * Cg, Kp, B * Tb, self.dt, a_rc=True, b_rc=True,
+                             av=view(J * Cg, Tb, Tp2 * Cg, (K - 1 - P) * Cg), bv=view(J * Cg, Tb, Tp2 * Cg), cv=view(Kp), out_f32=True,
+                             atomic=0, split_k=split, split_stride=G * nJ if split > 1 else 0, nbatch=G, batch_a=B * Tp2 * Cg,
+                             batch_b=B * Tp2 * Cg, batch_c=nJ, tr_mode=mode)
+                slabs = self.workspace("posconv_slabs", 4 * G * nJ, torch.float32)
+                if pick not in cands:
+                    ts = ops.measure_candidates({c: (lambda c=c: run(c[0], c[1], slabs)) for c in cands})
+                    pick = min(ts, key=ts.get)
+                    ops._tuned_set(key, pick)
+                    ops.TUNE_LIVE_KEYS.append(key)
+                dwJ = self.new(G * nJ, dt=torch.float32)
+                if pick[1] > 1:
+                    run(pick[0], pick[1], slabs)
+                    ops.reduce_slabs(slabs, pick[1], G * nJ, G * nJ, dwJ, accumulate=False)
+                else:
+                    run(pick[0], 1, dwJ)
+                dwp = self.new(n, dt=torch.float32)
+                ops.posconv_fold_dw(dwJ, dwp, G, Cg, K, J)
+                scratch = self.new(ops.wn_scratch_floats(d, Cg, K), dt=torch.float32)
+                ops.wn_bwd(dwp, self.P(v_n), self.P(g_n), sv["norm"], scratch, self.G(g_n), self.G(v_n), d, Cg, K)
+            wJf = self.new(G * J * Cg * Kp)
+            ops.posconv_pack_w(sv["wf"], wJf, G, Cg, K, J, False, self.dt)
+            tmp = self.new(G * B * Tq * Cg, dt=torch.float32)
+            ops.gemm(dyg, wJf, tmp, B * Tb, J * Cg, Kp, self.dt, av=view(J * Cg, Tb, Tp2 * Cg), bv=view(Kp), cv=view(J * Cg), out_f32=True,
+                     nbatch=G, batch_a=B * Tp2 * Cg, batch_b=J * Cg * Kp, batch_c=B * Tq * Cg)
+            dh = self.new(B * T, d)
+            ops.posconv_unpack(tmp, None, ds, None, dh, B, T, d, G, Tq, ACT_NONE, self.dt)
+            return dh
+        if train:
             dwp = self.new(n, dt=torch.float32)
             split = self._split(Cg, K * Cg * G, B * T)
             slabs = self.workspace("wgrad_slabs", split * n, torch.float32)

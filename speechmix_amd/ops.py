@@ -827,6 +827,21 @@ def group_pack(x, xg, B, T, Cc, G, K, pad_front, dtype):
                                    _stream()), "smx_group_pack")
 
 
+def posconv_pack_w(wp, out, G, Cg, K, J, flip, dtype):
+    L.check(L.lib().smx_posconv_pack_w(C.c_void_p(_ptr(wp)), C.c_void_p(_ptr(out)), G, Cg, K, J, int(flip), dtype, _stream()),
+            "smx_posconv_pack_w")
+
+
+def posconv_unpack(tmp, bias, resid, pre, y, B, T, Cc, G, Tq, act, dtype):
+    with _Span("posconv_unpack", B * T * Cc * (4 + _es(dtype) * (1 + (resid is not None) + (pre is not None)))):
+        L.check(L.lib().smx_posconv_unpack(C.c_void_p(_ptr(tmp)), C.c_void_p(_ptr(bias)), C.c_void_p(_ptr(resid)), C.c_void_p(_ptr(pre)),
+                                           C.c_void_p(_ptr(y)), B, T, Cc, G, Tq, act, dtype, _stream()), "smx_posconv_unpack")
+
+
+def posconv_fold_dw(dwJ, dwp, G, Cg, K, J):
+    L.check(L.lib().smx_posconv_fold_dw(C.c_void_p(_ptr(dwJ)), C.c_void_p(_ptr(dwp)), G, Cg, K, J, _stream()), "smx_posconv_fold_dw")
+
+
 def wn_scratch_floats(Cc, Cg, K):
     """Size of the `norm` / `scratch` buffers of wn_fwd / wn_bwd: K results followed by the partial rows of their reductions."""
     return K * (1 + L.lib().smx_wn_partial_blocks(Cc, Cg))
