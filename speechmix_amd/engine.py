@@ -296,6 +296,35 @@ class Engine:
                     del store[off]
                     self._gplan = None
 
+    # ------------------------------------------------------------------ small host -> device transfers
+    def h2d(self, arr, dtype=torch.int32):
+        """A small host array (SpecAugment rows, padded-frame rows, key lengths) to the device WITHOUT blocking the host: a
+        `.to(device)` from pageable memory is a synchronous copy - the host stands still until the stream has drained (measured
+        round 4: ~7 ms per training step at config 2, and the host's lead over the GPU, which the launch-bound LM stages live
+        on, is gone afterwards).  Staged through a ring of pinned buffers; a slot is reused only after its copy's event."""
+        t = torch.as_tensor(arr).to(dtype).reshape(-1)
+        if self.dev.type != "cuda":
+            return t.to(self.dev)
+        n = t.numel()
+        ring = self._persist.get("_h2d_ring")
+        if ring is None:
+            ring = self._persist["_h2d_ring"] = dict(slots=[None] * 8, ev=[None] * 8, i=0)
+        i = ring["i"]
+        ring["i"] = (i + 1) % len(ring["slots"])
+        buf = ring["slots"][i]
+        nbytes = n * t.element_size()
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()                  # (eight transfers old: long complete)
+        if buf is None or buf.numel() < nbytes:
+            buf = ring["slots"][i] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        host = buf[:nbytes].view(dtype)
+        host.copy_(t)
+        out = torch.empty(n, dtype=dtype, device=self.dev)
+        out.copy_(host, non_blocking=True)
+        ring["ev"][i] = torch.cuda.Event()
+        ring["ev"][i].record()
+        return out
+
     # ------------------------------------------------------------------ buffers / parameter access
     def new(self, *shape, dt=None):
         return torch.empty(shape, dtype=dt or self.tdt, device=self.dev)
@@ -1183,7 +1212,7 @@ class Engine:
         rows = np.flatnonzero(mask.reshape(-1))
         if rows.size == 0:
             return None
-        return torch.from_numpy(rows.astype(np.int32)).to(self.dev)
+        return self.h2d(rows.astype(np.int32))
 
     # ------------------------------------------------------------------ speech encoder
     def speech_fwd(self, wave, B, N, training, sample_lengths=None):
@@ -1203,7 +1232,7 @@ class Engine:
             frame_len = [max(1, min(T, ec.frames(int(n)))) for n in sample_lengths]
             if len(frame_len) != B:
                 raise ValueError("one length per clip")
-            klen = torch.tensor(frame_len, dtype=torch.int32, device=self.dev)
+            klen = self.h2d(np.asarray(frame_len, dtype=np.int32))
         sv["frame_len"] = frame_len
         if ec.feat_proj_layer_norm:
             fn, sv["fp_ln"] = self.ln_fwd(feat, ep + "feature_projection.layer_norm.weight",
@@ -1223,7 +1252,7 @@ class Engine:
         sv["pad_rows"] = None
         if frame_len is not None and min(frame_len) < T:           # "make sure padded tokens output 0" (TF:...wav2vec2.py:688-692)
             pad = np.concatenate([np.arange(n, T) + b * T for b, n in enumerate(frame_len)]).astype(np.int32)
-            pad_rows = torch.from_numpy(pad).to(self.dev)
+            pad_rows = self.h2d(pad)
             ops.mask_rows(h, pad_rows, pad_rows.numel(), self.zeros(d, dt=torch.float32), d, self.dt)
             sv["pad_rows"] = pad_rows
         s, sv["pc"] = self.posconv_fwd(h, B, T)
@@ -2076,7 +2105,7 @@ class Engine:
         # SpeechEncoderDecoderModel does with the reduced mask; the reference's own forward passes no mask to the LM)
         enc_klen = None
         if ex.get("lm_lengths") is not None and lm_mask:
-            enc_klen = torch.tensor(ex["lm_lengths"], dtype=torch.int32, device=self.dev)
+            enc_klen = self.h2d(np.asarray(ex["lm_lengths"], dtype=np.int32))
         lo = self.lm_losses(e, dec_ids, labels, B, S, Ld, text_ids=text_ids,
                             training=training if lm_training is None else lm_training, enc_klen=enc_klen, want_logits=want_logits)
         self.mark("fwd:lm")
