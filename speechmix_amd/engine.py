@@ -375,6 +375,8 @@ class Engine:
         ksteps = (Kred + 63) // 64
         # measured under rocprofv3 (tools/gpu_small_gemm.py trace): a 128x128 launch costs ~8 us + 0.8 us per K step, the slab
         # pass ~7 us more - up to 16 K steps (K <= 1024) one launch wins, beyond that ~8 K steps per split
+        if os.environ.get("SMX_FSPLIT_MID") == "1" and 256 < tiles <= 512 and ksteps >= 32 and Mo >= 4096:
+            return 2      # (experiment, round 4: the text encoder's M = 7 968, N = 768, K >= 2304 shapes as two K slices)
         if tiles > 256 or ksteps <= 16:
             return 1
         want = int(min(1024 // tiles, ksteps // 8, 24))

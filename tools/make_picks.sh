@@ -11,6 +11,8 @@ export SMX_TUNE=live SMX_TUNE_FILE=$PWD/$O/mi355x_picks.json
 rm -f $SMX_TUNE_FILE
 timeout 600 python3 bench.py --no-cpu-baseline --no-eval-leg > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 timeout 600 python3 bench.py --no-cpu-baseline --no-profile --eval-mode --steps 3 --warmup 3 > $O/bench_cfg2_eval.json 2>> $O/bench_cfg2.err
+# the backward of a data-parallel run leaves 40 CUs to RCCL (ops.PP_BACKWARD_CUS = 216): its keys carry that reserve
+SMX_PP_BACKWARD_CUS=216 timeout 600 python3 bench.py --no-cpu-baseline --no-profile --no-eval-leg --steps 3 --warmup 3 > $O/bench_cfg2_cus216.json 2>> $O/bench_cfg2.err
 for c in 4 5; do
   timeout 900 python3 tools/gpu_bench_cfg.py $c > $O/bench_cfg$c.txt 2>&1
 done
