@@ -303,7 +303,7 @@ class Engine:
         round 4: ~7 ms per training step at config 2, and the host's lead over the GPU, which the launch-bound LM stages live
         on, is gone afterwards).  Staged through a ring of pinned buffers; a slot is reused only after its copy's event."""
         t = torch.as_tensor(arr).to(dtype).reshape(-1)
-        if self.dev.type != "cuda":
+        if self.dev.type != "cuda" or os.environ.get("SMX_H2D_BLOCKING") == "1":
             return t.to(self.dev)
         n = t.numel()
         ring = self._persist.get("_h2d_ring")

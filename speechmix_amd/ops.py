@@ -19,8 +19,17 @@ def torch_dtype(dt):
     return _TORCH_DT[dt]
 
 
+_DEV_INDEX = None
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of PyTorch's CURRENT stream on this process's device.  `torch.cuda.current_stream().cuda_stream` costs ~8 us of
+    Python per call (device-index normalisation, a Stream object) - 7 ms of host time per training step at ~830 launches, where
+    the host enqueues only ~1.4 x faster than the GPU executes; the C accessor is the same value in ~0.3 us."""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()         # one process per GPU: fixed for the life of the process
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
 
 
 def _ptr(t):
