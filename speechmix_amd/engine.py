@@ -375,8 +375,12 @@ class Engine:
         ksteps = (Kred + 63) // 64
         # measured under rocprofv3 (tools/gpu_small_gemm.py trace): a 128x128 launch costs ~8 us + 0.8 us per K step, the slab
         # pass ~7 us more - up to 16 K steps (K <= 1024) one launch wins, beyond that ~8 K steps per split
-        if os.environ.get("SMX_FSPLIT_MID") == "1" and 256 < tiles <= 512 and ksteps >= 32 and Mo >= 4096:
-            return 2      # (experiment, round 4: the text encoder's M = 7 968, N = 768, K >= 2304 shapes as two K slices)
+        # round 4: 257-512 tiles of 128 x 128 (the text encoder's 7 968 x 768 outputs: 126 items of the 192-row kernel on 256 CUs).
+        # Two K slices pay from ~96 K steps on (the cross-attention K/V gradients' 7 968 x 768 x 9 216 data gradient: 260 -> 153 us
+        # + a 15-us slab epilogue); at K = 2304 / 3072 the GEMMs gain 12-18 us and the epilogue launch gives it back
+        # (SMX_FSPLIT_MID=1 splits those too: 32.02 vs 31.96 ms, profiles/r04_ab_runs.txt)
+        if 256 < tiles <= 512 and Mo >= 4096 and (ksteps >= 96 or (ksteps >= 32 and os.environ.get("SMX_FSPLIT_MID") == "1")):
+            return 2
         if tiles > 256 or ksteps <= 16:
             return 1
         want = int(min(1024 // tiles, ksteps // 8, 24))
