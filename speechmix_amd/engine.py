@@ -40,8 +40,9 @@ class HFHostRNG:
     LayerDrop (TF:...wav2vec2.py:712 `torch.rand([])`).  With no arguments the PROCESS-GLOBAL streams are used, so
     `np.random.seed(k)` / `torch.manual_seed(k)` reproduce HF's indices and keep decisions bit for bit
     (tests/test_train_mode_r3.py); `HFHostRNG.seeded(k)` owns private streams with the same draw order
-    (`StepRunner(..., seed=k)` installs one).  HF draws LayerDrop in train mode only in effect (`training and rand < p`
-    short-circuits here exactly as `self.training and ...` does there), so an eval pass consumes nothing from either stream."""
+    (`StepRunner(..., seed=k)` installs one).  HF evaluates `torch.rand([])` once per layer in EVAL mode too (the draw precedes
+    `self.training and ...`), so `Engine.speech_fwd` draws unconditionally as well: the stream stays aligned with HF's across
+    interleaved evaluation passes."""
 
     def __init__(self, np_state=None, torch_gen=None):
         self.np, self.tg = np_state, torch_gen
@@ -1275,8 +1276,10 @@ class Engine:
         sv["layers"] = []
         hidden = [x]
         for i in range(self.L):
-            # TF:...wav2vec2.py:709-723: one draw per layer (HF draws in eval mode too; only train-mode draws decide anything)
-            if training and self.host_rng.layerdrop() < ec.layerdrop:
+            # TF:...wav2vec2.py:709-723: one draw per layer - HF draws in eval mode too (`torch.rand([])` precedes `self.training and`),
+            # so the draw is unconditional here as well; only train-mode draws decide anything
+            draw = self.host_rng.layerdrop()
+            if training and draw < ec.layerdrop:
                 sv["layers"].append(None)
                 hidden.append(x)
                 continue
