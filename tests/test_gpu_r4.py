@@ -215,3 +215,47 @@ def test_first_write_stores_equals_zero_fill_then_accumulate():
             if any(name.startswith(f"encoder_model.encoder.layers.{i}.") for i in d1):
                 assert not b.any(), (step, name)
     assert dropped_any           # (LayerDrop 0.4 over 6 steps x 4 layers: the case this test exists for did occur)
+
+
+@pytest.mark.parametrize("k,s", [(3, 2), (2, 2)])
+def test_conv_data_gradient_in_the_forward_layout_vs_fp32_reference(k, s):
+    """Round 4 (`Engine.cnn_bwd`, `smx_pack_conv_w_dgrad`): the data gradient of a strided Conv1d as one forward-layout GEMM per input
+    residue - A = runs of the zero-padded output gradient, B = the residue's taps transposed into a K-contiguous operand, C written
+    through the strided per-residue view, x GELU'(saved pre-activation) in the epilogue - at the feature extractor's real widths
+    (512 -> 512 channels, 8 clips x 2 s: 255 968-row GEMMs on the 256-wide kernels), against fp32
+    `conv_transpose1d(dy, w) * gelu'(pre)`.  Bound: bf16 rounding of the output (2^-7 of the largest entry)."""
+    import torch.nn.functional as F
+    from speechmix_amd import ops
+    from speechmix_amd.ops import ACT_GELU, view
+    dev = torch.device("cuda:0")
+    B, Tin, Cin, Co, PAD = 8, 6399, 512, 512, 2
+    To = (Tin - k) // s + 1
+    Tp = To + 2 * PAD
+    g = torch.Generator().manual_seed(k * 10 + s)
+    w = (torch.randn(Co, Cin, k, generator=g) * 0.03)
+    dy = (torch.randn(B, To, Co, generator=g) * 0.5).bfloat16()
+    pre = (torch.randn(B, Tin, Cin, generator=g)).bfloat16()
+    ref = F.conv_transpose1d(dy.float().transpose(1, 2), w.bfloat16().float(), stride=s)              # [B, Cin, (To-1) s + k]
+    ref = F.pad(ref, (0, Tin - ref.shape[-1])).transpose(1, 2)
+    x = pre.float()
+    gelu_grad = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    ref = ref * gelu_grad
+    dpre = torch.zeros(B, Tp, Co, dtype=torch.bfloat16, device=dev)
+    dpre[:, PAD:PAD + To] = dy.to(dev)
+    wd = torch.empty(Co * Cin * k, dtype=torch.bfloat16, device=dev)
+    ops.pack_conv_w_dgrad(w.to(dev), wd, Co, Cin, k, s, ops.BF16)
+    pre_d = pre.to(dev).contiguous()
+    out = torch.zeros(B, Tin, Cin, dtype=torch.bfloat16, device=dev)
+    off = 0
+    for r in range(s):
+        nj = len(range(r, k, s))
+        U = (Tin - 1 - r) // s + 1
+        wd_r = wd[off:off + Cin * nj * Co]
+        off += Cin * nj * Co
+        ops.gemm(dpre, wd_r, out, B * U, Cin, nj * Co, ops.BF16, av=view(Co, U, Tp * Co, (PAD - (nj - 1)) * Co),
+                 cv=view(s * Cin, U, Tin * Cin, r * Cin), ev=view(s * Cin, U, Tin * Cin, r * Cin), aux_in=pre_d, act=ACT_GELU)
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs().max().item()
+    sc = ref.abs().max().item()
+    print(f"conv dgrad k={k} s={s}: err {err:.3e} / {sc:.3e}")
+    assert err <= 2 ** -7 * sc
