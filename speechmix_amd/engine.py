@@ -548,7 +548,9 @@ class Engine:
         """rows: group only the weight gradients over exactly `rows` rows, also while the LM stage's second stream is active
         (round 4: a decoder layer's seven M = B x L weight gradients - 144 output tiles of 256 x 256, 16 K tiles deep - as one
         launch on that stream instead of seven split-K launches + their slab reductions)."""
-        on = _WGRAD_GROUP and self.dt == BF16 and (rows is None or os.environ.get("SMX_LM_WGRAD_GROUP", "1") != "0")
+        # (the LM-stage form measured 33.10 vs 32.97 ms: a 144-CU persistent launch beside the decoder's small-grid chain takes its
+        # CUs away - off unless SMX_LM_WGRAD_GROUP=1)
+        on = _WGRAD_GROUP and self.dt == BF16 and (rows is None or os.environ.get("SMX_LM_WGRAD_GROUP", "0") == "1")
         self._wg_group = [] if on else None
         self._wg_rows = rows if on else None
 
