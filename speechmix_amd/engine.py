@@ -657,7 +657,7 @@ class Engine:
         return dict(drop=drop, gb=self.G(bname))
 
     # ------------------------------------------------------------------ attention block (self or cross)
-    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None, drop=None, klen=None):
+    def attn_fwd(self, x, kvsrc, B, Tq, Tk, d, H, names, causal, scale, bias=None, drop=None, klen=None, masks=None):
         """names: dict(q,k,v,o -> (weight, bias|None)).  klen: int32 [B] on the device - keys >= klen[b] are padding (stays in the
         descriptor: backward masks the same keys).  Returns (o [B*Tq, d], saved)."""
         Mq, Mk = B * Tq, B * Tk
@@ -668,7 +668,7 @@ class Engine:
             wqkv = self.st.cat([qn[0], kn[0], vn[0]])
             bqkv = self.st.cat([qn[1], kn[1], vn[1]], "p32") if qn[1] else None
             qkv = self.lin(x, wqkv, bqkv, Mq, 3 * d, d)
-            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop, klen=klen)
+            desc = ops.AttnDesc(B, H, Tq, Tk, hd, causal, scale, bias, drop=drop, klen=klen, masks=masks)
             desc.set("Q", qkv, 0, Tq * 3 * d, 3 * d)
             desc.set("K", qkv, d, Tk * 3 * d, 3 * d)
             desc.set("V", qkv, 2 * d, Tk * 3 * d, 3 * d)
@@ -786,7 +786,7 @@ class Engine:
         return dh
 
     def layer_fwd(self, x, B, T, d, H, F, nm, pre_ln, act, eps, causal=False, scale=None, enc=None, Tk=None, rms=False,
-                  bias=None, cross_bias=None, drop=None, klen=None, enc_klen=None):
+                  bias=None, cross_bias=None, drop=None, klen=None, enc_klen=None, premask=None):
         """One transformer layer.  nm: dict with keys attn{q,k,v,o}, ln1, [xattn, lnx], fc1, fc2, ln2.
         drop = (hidden p, attention-probability p, activation p) in training mode, else None.  Sites (identical in
         TF:models/wav2vec2/modeling_wav2vec2.py:575-654, TF:models/bart/modeling_bart.py:260-475, T5 blocks): the
@@ -798,8 +798,11 @@ class Engine:
         sv["d_o"], sv["d_xo"] = self._dp(ph), (self._dp(ph) if enc is not None else None)
         d_act, d_out = self._dp(pf), self._dp(ph)
         da, dxa = self._dp(pa), (self._dp(pa) if enc is not None else None)
+        amask = None
+        if premask is not None and da is not None and premask["p"] == da[0]:
+            da, amask = (da[0], premask["seed"]), premask["masks"]      # the bit matrices generated beside the last optimizer step
         if not pre_ln:
-            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen)
+            o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen, masks=amask)
             s1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x, drop=sv["d_o"])
             h, sv["ln1"] = self.ln_fwd(s1, nm["ln1"][0], nm["ln1"][1], M, d, eps)
             if enc is not None:
@@ -811,7 +814,7 @@ class Engine:
             y, sv["ln2"] = self.ln_fwd(s3, nm["ln2"][0], nm["ln2"][1], M, d, eps)
         else:
             n1, sv["ln1"] = self.ln_fwd(x, nm["ln1"][0], nm["ln1"][1], M, d, eps, rms=rms)
-            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen)
+            o, sv["a"] = self.attn_fwd(n1, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen, masks=amask)
             x1 = self.lin(o, self.W(nm["attn"]["o"][0]), self._b(nm["attn"]["o"][1]), M, d, d, resid=x, drop=sv["d_o"])
             if enc is not None:
                 nx, sv["lnx"] = self.ln_fwd(x1, nm["lnx"][0], nm["lnx"][1], M, d, eps, rms=rms)
@@ -1223,6 +1226,56 @@ class Engine:
             return None
         return self.h2d(rows.astype(np.int32))
 
+    # ------------------------------------------------------------------ attention dropout masks ahead of time (round 4)
+    # The keep masks of the speech encoder's attention-probability dropout are bit matrices that depend on (seed, shape) only:
+    # 41 us of VALU work per layer and step at config 2, on the critical path right before every attention forward.  The
+    # optimizer step that ends a training step is HBM-bound (Adafactor: 1.4 ms at ~3.6 TB/s with the vector units mostly idle),
+    # so `pregen_attention_masks` generates the NEXT step's masks for all layers on a second stream beside it; the next forward
+    # takes a layer's pair if batch and frame count still match (`_take_premask`), otherwise - first step, another batch shape,
+    # eval mode, gradient accumulation's inner micro-batches - the mask is generated in place as before.  A dropped layer's pair
+    # is simply not used.  SMX_PREGEN_MASKS=0: off.
+    def pregen_attention_masks(self, B, T):
+        ec = self.ec
+        p = float(ec.attention_dropout)
+        if (self.dt != BF16 or p <= 0 or self.dev.type != "cuda" or os.environ.get("SMX_PREGEN_MASKS") == "0"
+                or ec.hidden_size // ec.num_attention_heads != 64):
+            self._premask = None
+            return
+        st = getattr(self, "_mask_stream", None)
+        if st is None:
+            st = self._mask_stream = torch.cuda.Stream()
+        old = getattr(self, "_premask", None) or {}
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())          # behind the backward that still reads the previous pairs
+        st.wait_event(ev)
+        new = dict(B=B, T=T, layers={})
+        with torch.cuda.stream(st):
+            for i in range(self.L):
+                seed = int(self.drop_rng.integers(1, 2 ** 32 - 1))
+                prev = (old.get("layers") or {}).get(i)
+                masks = ops.attn_dropout_masks(B, ec.num_attention_heads, T, T, 64, p, seed, self.dt, self.dev,
+                                               reuse=prev["masks"] if prev else None)
+                if masks is None:
+                    self._premask = None
+                    return
+                new["layers"][i] = dict(p=p, seed=seed, masks=masks)
+            new["ev"] = torch.cuda.Event()
+            new["ev"].record(st)
+        self._premask = new
+
+    def _take_premask(self, i, B, T):
+        pm = getattr(self, "_premask", None)
+        if pm is None or pm["B"] != B or pm["T"] != T:
+            return None
+        if pm.get("ev") is not None:                     # first use in this forward: the main stream waits for the generation
+            torch.cuda.current_stream().wait_event(pm["ev"])
+            pm["ev"] = None
+        e = pm["layers"].get(i)
+        if e is None or e.get("used"):
+            return None                                  # (a pair serves ONE forward; its buffers are overwritten by the next pregen)
+        e["used"] = True
+        return e
+
     # ------------------------------------------------------------------ speech encoder
     def speech_fwd(self, wave, B, N, training, sample_lengths=None):
         """sample_lengths: per-clip count of real (unpadded) samples = a right-padded `attention_mask` into the speech encoder.
@@ -1231,6 +1284,8 @@ class Engine:
         convolution and masks them as attention keys in every layer; the CNN itself still sees the padding."""
         ec, ep = self.ec, self.ep
         d, eps = ec.hidden_size, ec.layer_norm_eps
+        if not training:
+            self._premask = None                        # (pairs generated for a training step that did not come)
         feat, cnn_sv = self.cnn_fwd(wave, B, N)
         T = cnn_sv["Ts"][-1]
         C = ec.conv_dim[-1]
@@ -1287,7 +1342,7 @@ class Engine:
                 continue
             ops.GEMM_TAG = "enc_layer"
             x, lsv = self.layer_fwd(x, B, T, d, ec.num_attention_heads, ec.intermediate_size, self._w2v2_layer_names(i),
-                                    stable, act, eps, drop=drop, klen=klen)
+                                    stable, act, eps, drop=drop, klen=klen, premask=self._take_premask(i, B, T))
             ops.GEMM_TAG = None
             sv["layers"].append(lsv)
             hidden.append(x)

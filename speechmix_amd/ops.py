@@ -637,8 +637,9 @@ _NORM_WS = {}
 class AttnDesc:
     """Strided description of Q/K/V/O living inside fused projection buffers (element units)."""
 
-    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None, drop=None, klen=None):
-        """klen: optional int32 [B] device tensor - keys at positions >= klen[b] are padding (right-padded attention mask)."""
+    def __init__(self, B, H, Tq, Tk, D, causal, scale, bias=None, drop=None, klen=None, masks=None):
+        """klen: optional int32 [B] device tensor - keys at positions >= klen[b] are padding (right-padded attention mask).
+        masks = (mask_q, mask_k): the dropout bit matrices of `drop`, already generated (attn_dropout_masks)."""
         self.p = L.AttnParams()
         p = self.p
         p.B, p.H, p.Tq, p.Tk, p.D, p.causal, p.scale = B, H, Tq, Tk, D, int(causal), scale
@@ -649,6 +650,9 @@ class AttnDesc:
             assert klen.dtype == torch.int32 and klen.numel() == B and klen.is_cuda
         p.klen = _ptr(klen)
         self._keep = [bias, klen]
+        if masks is not None:
+            p.mask_q, p.mask_k = _ptr(masks[0]), _ptr(masks[1])
+            self._keep += list(masks)
 
     def set(self, name, tensor, elem_off, batch_stride, ld):
         """name in Q K V O dO dQ dK dV"""
@@ -657,6 +661,27 @@ class AttnDesc:
         setattr(self.p, pre + "_bs", batch_stride)
         setattr(self.p, pre + "_ld", ld)
         self._keep.append(tensor)
+
+
+def attn_dropout_masks(B, H, Tq, Tk, D, p, seed, dtype, device, reuse=None):
+    """The keep mask of one attention call's probability dropout as bit matrices (both orientations), generated on the CURRENT
+    stream.  -> (mask_q, mask_k) int32 tensors, or None when this (dtype, head_dim) path hashes in-kernel.  reuse: a previous
+    pair of the same sizes to overwrite."""
+    a = L.AttnParams()
+    a.B, a.H, a.Tq, a.Tk, a.D = B, H, Tq, Tk, D
+    a.drop_p, a.drop_seed = p, seed
+    nq, nk = C.c_longlong(0), C.c_longlong(0)
+    L.check(L.lib().smx_attn_mask_words(C.byref(a), dtype, C.byref(nq), C.byref(nk)), "smx_attn_mask_words")
+    if not nq.value:
+        return None
+    if reuse is not None and reuse[0].numel() == nq.value and reuse[1].numel() == nk.value:
+        mq, mk = reuse
+    else:
+        mq = torch.empty(nq.value, dtype=torch.int32, device=device)
+        mk = torch.empty(nk.value, dtype=torch.int32, device=device)
+    a.mask_q, a.mask_k = _ptr(mq), _ptr(mk)
+    L.check(L.lib().smx_attn_dropout_mask(C.byref(a), _stream()), "smx_attn_dropout_mask")
+    return mq, mk
 
 
 def attention_fwd(desc, lse, dtype):

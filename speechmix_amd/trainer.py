@@ -157,6 +157,9 @@ class StepRunner:
         if not last:
             return out["loss"]
         self.reducer.finish()
+        if m.training and m.encoder_model.training and self.grad_accum == 1:
+            # the next step's attention-dropout masks, generated beside the (HBM-bound) optimizer step on a second stream
+            eng.pregen_attention_masks(wave.shape[0], out["T"])
         self.t += 1
         lr = self.current_lr()
         inv_world = 1.0 / self.world
