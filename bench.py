@@ -267,6 +267,15 @@ def main():
     B = args.batch
     wave, labels = synth_batch(B, model.decoder_model.config.vocab_size, rank, device)
 
+    # Set-up (untimed, ahead of the W warm-up steps): the step's forward + backward are replayed from captured HIP graphs
+    # (speechmix_amd/graphs.py; SMX_STEP_GRAPHS=0: eager) once the configuration has run a few eager steps - kernel picks, the
+    # first-write gradient ranges - so the capture must not land inside the timed region whatever W is.
+    setup_steps = 0
+    from speechmix_amd import graphs as _graphs
+    if _graphs.ENABLED:
+        while runner._graphs is None and runner._graph_failures < 2 and setup_steps < 8:
+            loss = runner.step(wave, labels)
+            setup_steps += 1
     for _ in range(args.warmup):
         loss = runner.step(wave, labels)
     if world > 1:
@@ -283,6 +292,16 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    # The host's share of a step: wall time of `runner.step` itself with the queue EMPTY before it (over K back-to-back steps the
+    # host runs into the command queue's back-pressure and measures the GPU instead); median of 5, outside the timed region
+    host_ms = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        runner.step(wave, labels)
+        host_ms.append(1e3 * (time.perf_counter() - th))
+    torch.cuda.synchronize()
+    host_elapsed = sorted(host_ms)[2] * 1e-3 * args.steps
     # Roofline pass: the same K steps again with a HIP-event pair around every GEMM launch (on the launch stream).
     # Kept out of the timed pass because ~370 event pairs per step cost ~4 % of the step.
     prof = oprof = None
@@ -312,7 +331,7 @@ def main():
     eval_ms = None
     if not args.eval_mode and not args.no_eval_leg:
         model.eval()
-        for _ in range(2):
+        for _ in range(6 if _graphs.ENABLED else 2):          # (another configuration: its own eager steps + capture)
             runner.step(wave, labels)
         if world > 1:
             dist.barrier()
@@ -345,7 +364,14 @@ def main():
                 "config": {"workload": f"SpeechMixEED wav2vec2-base + bart-base, {B} x 10 s clips/GPU, down_scale=2, "
                                        "32 label tokens, fwd+bwd+allreduce+clip+" + {"adafactor": "Adafactor", "adamw": "AdamW"}[args.optimizer] + ", " + mode,
                            "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
-                "final_loss": round(final_loss, 4)}
+                "final_loss": round(final_loss, 4),
+                "host": {"enqueue_ms_per_step": round(1e3 * host_elapsed / args.steps, 3),
+                         "step_graphs": runner._graphs is not None,
+                         "graphs_per_step": len(runner._graphs.graphs) if runner._graphs is not None else 0,
+                         "setup_steps_before_warmup": setup_steps,
+                         "note": "wall time of one StepRunner.step call on the host with an empty queue ahead of it (median of 5, outside "
+                                 "the timed region); forward + backward replayed from captured HIP graphs when step_graphs is true "
+                                 "(speechmix_amd/graphs.py)"}}
         if in_sync is not None:
             line["params_in_sync"] = in_sync
         if world > 1:
@@ -427,6 +453,17 @@ def main():
                                          "ms_per_step": round(enc["total_ms"] / args.steps, 3),
                                          "launches_per_step": round(enc["launches"] / args.steps, 1),
                                          "what": "speech-encoder transformer layers' Linear GEMMs: fwd + dgrad + wgrad (HIP events per launch)"}
+            # what the review reads first, inside `roofline`: the encoder-layer GEMMs (north_star's 0.40 is
+            # defined on them), all GEMMs, the whole step (executed GEMM + attention flops of the instrumented steps / the TIMED
+            # step time / peak) and the peaks this box's probes measure
+            att_fl = sum(v["flops"] for k, v in osum.items() if k.startswith("attention")) / args.steps
+            step_fl = all_fl / args.steps + att_fl
+            line["roofline"].update(
+                encoder_gemms_frac=round(enc["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4) if enc["launches"] else None,
+                all_gemms_frac=round(all_fl / (all_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                step_frac=round(step_fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                step_flops=round(step_fl),
+                step_frac_note="executed GEMM + attention flops per step (instrumented train-mode steps: LayerDrop skips layers) / ms_per_step / peak")
             line["gemm_variants"] = {ops.GemmProfile.name(k): {"tflops": round(v["tflops"], 1),
                                                                   "ms_per_step": round(v["total_ms"] / args.steps, 3),
                                                                   "launches_per_step": round(v["launches"] / args.steps, 1),
@@ -438,6 +475,9 @@ def main():
         if not args.no_profile:
             try:
                 line["peaks_measured"] = measured_peaks(device)
+                if "roofline" in line:
+                    line["roofline"].update(mfma_peak_measured=line["peaks_measured"]["mfma_bf16_tflops"],
+                                            hbm_peak_measured=line["peaks_measured"]["hbm_copy_GBps"])
             except Exception as e:          # a reporting extra must never cost the bench line
                 line["peaks_measured"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:

@@ -196,6 +196,16 @@ int smx_add_f32_into(const float* src, void* dst, long long n, int dtype, hipStr
  * fused sites (GEMM epilogue, norm output, attention probabilities) and this stand-alone kernel use the same function,
  * so a backward pass regenerates the forward mask from (p, seed) instead of storing it. */
 int smx_dropout(const void* x, void* out, long long n, float p, unsigned seed, int dtype, hipStream_t stream);
+/* The STEP KEY (round 5): every kernel that hashes a dropout mask uses (its seed argument + the key), one device word the
+ * library owns and this call rewrites on `stream` (0 until first set: a seed then means what it always meant).  A training
+ * step captured into a HIP graph bakes its seed arguments; setting a fresh key ahead of every replay is what makes the
+ * replayed step draw fresh masks (the reference draws from torch's Philox stream per call: TF sites above).  Rows of
+ * smx_mask_rows / smx_mask_rows_bwd lists that are negative are skipped (fixed-capacity SpecAugment row lists of such steps). */
+int smx_set_step_key(unsigned key, hipStream_t stream);
+/* dst[0 .. bytes) = src[0 .. bytes) as one kernel on `stream` (16-byte aligned; src may be pinned host memory): the copies of a
+ * replayed step - inputs, SpecAugment rows, a LayerDrop-dropped layer's pass-through (TF:models/wav2vec2/modeling_wav2vec2.py:
+ * 709-723 skips the layer; the captured graphs of the neighbours read fixed buffers) - without the runtime's copy path */
+int smx_copy_bytes(const void* src, void* dst, long long bytes, hipStream_t stream);
 
 /* layer-weighted sum of the L+1 encoder hidden states (ref:speechmix/hf_model.py:411-423; ref:speechmix/model.py:150-157) */
 typedef struct SmxWsumParams {

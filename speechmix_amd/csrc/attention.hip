@@ -66,6 +66,7 @@ __device__ __forceinline__ void att_drop4(const SmxAttnParams& p, unsigned rb, i
 #define SIMPLE_MAXD 128
 template <typename T>
 __global__ void attn_fwd_simple(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.B * p.H * p.Tq) return;
     const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
@@ -114,6 +115,7 @@ __global__ void attn_delta_kernel(SmxAttnParams p) {
 
 template <typename T>
 __global__ void attn_bwd_dq_simple(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.B * p.H * p.Tq) return;
     const int q = idx % p.Tq, h = (idx / p.Tq) % p.H, b = idx / (p.Tq * p.H);
@@ -143,6 +145,7 @@ __global__ void attn_bwd_dq_simple(SmxAttnParams p) {
 
 template <typename T>
 __global__ void attn_bwd_dkv_simple(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.B * p.H * p.Tk) return;
     const int k = idx % p.Tk, h = (idx / p.Tk) % p.H, b = idx / (p.Tk * p.H);
@@ -181,6 +184,7 @@ __global__ void attn_bwd_dkv_simple(SmxAttnParams p) {
 // produce it); delta must have been written (the dQ kernel does).  The tables are tiny (T5 runs on S <= 249 keys).
 template <typename T>
 __global__ void attn_dbias_kernel(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)p.H * p.Tq * p.Tk) return;
     const int k = (int)(idx % p.Tk), q = (int)((idx / p.Tk) % p.Tq), h = (int)(idx / ((long long)p.Tk * p.Tq));
@@ -307,6 +311,7 @@ __device__ __forceinline__ bf16x8_t load_row_frag(const bf16_t* base, long long 
 // probabilities of a 16x16 block are directly the B operand of the P V product ("pair" k-slot mapping, see frag_tr).
 template <int U>
 __global__ __launch_bounds__(256, U == 1 ? 4 : 2) void attn_fwd_bf16(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     __shared__ __attribute__((aligned(16))) char sK[2][8192];
     __shared__ __attribute__((aligned(16))) char sV[2][8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(256, U == 1 ? 4 : 2) void attn_fwd_bf16(SmxAttnPara
 // dK/dV kernel that follows it on the stream.
 template <int U>
 __global__ __launch_bounds__(256, U == 1 ? 3 : 1) void attn_bwd_dq_bf16(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     __shared__ __attribute__((aligned(16))) char sK[2][8192];
     __shared__ __attribute__((aligned(16))) char sV[2][8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(256, U == 1 ? 3 : 1) void attn_bwd_dq_bf16(SmxAttnP
 // reductions over queries.
 template <int U>
 __global__ __launch_bounds__(256, U == 1 ? 2 : 1) void attn_bwd_dkv_bf16(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     __shared__ __attribute__((aligned(16))) char sQ[2][8192];
     __shared__ __attribute__((aligned(16))) char sDO[2][8192];
     __shared__ float sNlse2[2][64];
@@ -843,3 +850,5 @@ extern "C" int smx_attn_bias_scatter(const float* dbias, const int* bucket, floa
 
 // ABI self-description (checked by the ctypes binding against its struct mirrors)
 extern "C" int smx_sizeof_SmxAttnParams(void) { return (int)sizeof(SmxAttnParams); }
+
+SMX_STEP_KEY_TU(attention)

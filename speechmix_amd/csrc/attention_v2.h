@@ -46,6 +46,7 @@ __device__ __forceinline__ void a2_mask_pairs(std::integer_sequence<int, Js...>,
     (a2_mask_pair<Js>(p, kw, rb, th, qok, w, mine_lo, mine_hi), ...);
 }
 __global__ __launch_bounds__(256) void attn_mask_kernel(SmxAttnParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int KW = A2_QW(p.Tk), QW = A2_QW(p.Tq);
     const int kw = blockIdx.x * 4 + wave;                 // key word

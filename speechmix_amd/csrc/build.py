@@ -42,7 +42,8 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = ["hipcc"] + FLAGS + ["-I", HERE, "-c", src, "-o", obj]
+        # SMX_TU: the file's stem - names the translation unit's step-key word (smx_common.h)
+        cmd = ["hipcc"] + FLAGS + ["-DSMX_TU=" + os.path.basename(src)[:-4], "-I", HERE, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 

@@ -79,6 +79,7 @@ __device__ __forceinline__ void epilogue4(const SmxGemmParams& p, long long zc, 
 
 template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(SmxGemmParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -262,6 +263,7 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
     }
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    const unsigned dseed = smx_dseed(p.drop_p, p.drop_seed);          // + the step key (the kernels hand in the kernarg copy of p)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
@@ -279,7 +281,7 @@ __device__ __forceinline__ void epilogue_staged(const SmxGemmParams& p, f32x4_t 
             const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(wbuf + lr * 256 + (((2 * cc + 1) ^ (lr & 15)) << 4));
             if (m < p.M && n < p.N) {
                 float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                epilogue_row8(p, zc, ze, m, n, x, bs, th, inv_keep);
+                epilogue_row8(p, zc, ze, m, n, x, bs, th, inv_keep, dseed);
             }
         }
     }
@@ -312,6 +314,7 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
     const bool drop = EPI != PP_EPI_F32 && p.drop_p > 0.f;
+    const unsigned dseed = smx_dseed(p.drop_p, p.drop_seed);          // + the step key (the kernels hand in the kernarg copy of p)
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && !F32_PLAIN && p.atomic == 2;
     const bool has_aux = EPI == PP_EPI_ACT && p.aux_out;
@@ -418,14 +421,14 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                 if (EPI == PP_EPI_ACT) {
                     const unsigned didx = (unsigned)((long long)m * p.N + n + zc);
                     if constexpr (sg) {       // side tensor = local derivative: activation, mask and derivative pair by pair
-                        const uint4 d = act_fwd_grad_drop8(x, act, drop, p.drop_seed, didx, th, inv_keep);
+                        const uint4 d = act_fwd_grad_drop8(x, act, drop, dseed, didx, th, inv_keep);
                         if (has_aux && ok[qi]) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[qi]) = d;
                     } else {
                         if (has_aux && ok[qi])
                             *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.aux_out) + eb[qi]) =
                                 make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
                         act_fwd8(x, act);
-                        if (drop) smx_drop_mul8(p.drop_seed, didx, th, inv_keep, x);
+                        if (drop) smx_drop_mul8(dseed, didx, th, inv_keep, x);
                     }
                 }
                 if (EPI == PP_EPI_ACTGRAD) {
@@ -440,10 +443,10 @@ __device__ __forceinline__ void epilogue_staged_fast(const SmxGemmParams& p, f32
                                       __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
                                       __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
                         act_grad_mul8(x, s, act);
-                        if (drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
+                        if (drop) smx_drop_mul8(dseed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
                     }
                 }
-                if (EPI == PP_EPI_LINEAR && drop) smx_drop_mul8(p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
+                if (EPI == PP_EPI_LINEAR && drop) smx_drop_mul8(dseed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep, x);
                 if (EPI == PP_EPI_LINEAR && has_res) {
                     const uint4 u = side[qi];
                     x[0] += __uint_as_float(u.x << 16); x[1] += __uint_as_float(u.x & 0xffff0000u);
@@ -691,6 +694,7 @@ int smx_gemm_fr(const SmxGemmParams& p, hipStream_t stream);   // gemm_fr.hip
 // fp32: simple 64x64x16 VALU tile kernel with fully generic operand addressing.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_f32_kernel(SmxGemmParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     __shared__ float As[16][65];
     __shared__ float Bs[16][65];
     const int tid = threadIdx.x;
@@ -845,6 +849,7 @@ extern "C" int smx_reduce_slabs_many(const float* const* slabs, float* const* ds
 // dropout, residual, aux_out, bf16 / fp32 / accumulate).  slabs: nsplit x [M, ldn] fp32, rows padded to ldn % 8 == 0.
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SmxGemmParams p, const float* __restrict__ slabs, int nsplit,
                                                               long long stride, int ldn) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int chunks = (p.N + 7) >> 3;
     const long long total = (long long)p.M * chunks;
     const unsigned th = smx_thresh24(p.drop_p);
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(SmxGemmParams p, c
         float bs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) bs[e] = (p.bias && n + e < p.N) ? p.bias[n + e] : 0.f;
-        epilogue_row8<false, true>(p, 0, 0, m, n, x, bs, th, inv_keep);
+        epilogue_row8<false, true>(p, 0, 0, m, n, x, bs, th, inv_keep, p.drop_seed);
     }
 }
 extern "C" int smx_gemm_splitk_epilogue(const SmxGemmParams* pp, const float* slabs, int nsplit, long long stride, int ldn,
@@ -993,3 +998,5 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
 
 // ABI self-description (checked by the ctypes binding against its struct mirrors)
 extern "C" int smx_sizeof_SmxGemmParams(void) { return (int)sizeof(SmxGemmParams); }
+
+SMX_STEP_KEY_TU(gemm)

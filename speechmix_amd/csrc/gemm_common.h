@@ -182,7 +182,8 @@ __device__ __forceinline__ void st8(float* p, const float v[8]) {
 // class-specialised epilogues - the launcher checks - and keep this path's register footprint)
 template <bool ASM_ST = false, bool SG = false>
 __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long zc, long long ze, int m, int n, float x[8],
-                                              const float bs[8], unsigned th, float inv_keep) {
+                                              const float bs[8], unsigned th, float inv_keep, unsigned dseed) {
+    // dseed: the seed the masks are hashed with = the launch's drop_seed + the step key (smx_dseed; the caller reads the key once)
     const long long base = zc + view_off(p.c, m) + n;
     const bool side = p.resid || p.aux_out || p.aux_in;
     const long long sb = side ? ze + view_off(p.e, m) + n : 0;
@@ -208,17 +209,17 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
                 act_grad_mul8(x, a, act);
             }
         } else if (fused) {
-            const uint4 d = act_fwd_grad_drop8(x, act, p.drop_p > 0.f, p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
+            const uint4 d = act_fwd_grad_drop8(x, act, p.drop_p > 0.f, dseed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
             if (ASM_ST) st_b128(aux_out + sb, d); else *reinterpret_cast<uint4*>(aux_out + sb) = d;
         } else if (act) {
             act_fwd8(x, act);
         }
         if (p.drop_p > 0.f && !sg) {
             const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
-            if (!(idx & 1u)) smx_drop_mul8(p.drop_seed, idx, th, inv_keep, x);
+            if (!(idx & 1u)) smx_drop_mul8(dseed, idx, th, inv_keep, x);
             else
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(p.drop_seed, idx + e, th, inv_keep);
+                for (int e = 0; e < 8; ++e) x[e] *= smx_drop_mul(dseed, idx + e, th, inv_keep);
         }
         if (resid) {
             float r[8];
@@ -248,7 +249,7 @@ __device__ __forceinline__ void epilogue_row8(const SmxGemmParams& p, long long 
     // ragged / unaligned tail (LM head with V % 8 != 0, odd views): element-wise
     for (int e = 0; e < nv; ++e) {
         float v = x[e];
-        const float mk = (p.drop_p > 0.f && !(aux_in && sg)) ? smx_drop_mul(p.drop_seed, (unsigned)((long long)m * p.N + n + e + zc), th, inv_keep) : 1.f;
+        const float mk = (p.drop_p > 0.f && !(aux_in && sg)) ? smx_drop_mul(dseed, (unsigned)((long long)m * p.N + n + e + zc), th, inv_keep) : 1.f;
         if (aux_out) {
             const float s = sg ? act_grad(v, act) * mk : v;
             if (ASM_ST) st_b16(aux_out + sb + e, f2bf(s)); else aux_out[sb + e] = f2bf(s);

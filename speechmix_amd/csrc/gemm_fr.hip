@@ -270,3 +270,5 @@ int smx_gemm_group_fr(const SmxGemmGroup& grp, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_bf16_fr_group_kernel<true, true, PP_EPI_F32>), grid, dim3(512), PP_LDS_BYTES, stream, grp);
     SMX_CHECK_LAUNCH();
 }
+
+SMX_STEP_KEY_TU(gemm_fr)

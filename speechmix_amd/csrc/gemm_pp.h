@@ -347,6 +347,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[NB][4], int mw0, int 
     }
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
+    const unsigned dseed = smx_dseed(p.drop_p, p.drop_seed);          // + the step key (smx_common.h), read once per item
     // rolled over the 16 (row block, column half) pieces - ONE copy of the row epilogue in the binary; the accumulators
     // are picked by a wave-uniform switch so that every register index stays static
 #pragma clang loop unroll(disable)
@@ -375,7 +376,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4_t (&acc)[NB][4], int mw0, int 
         const int a8 = it >> 1, ch = it & 1;
         const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
         const int n = nw0 + ch * 32 + g * 8;
-        if (m < p.M && n < p.N) epilogue_row8<true>(p, zc, ze, m, n, x, b8, th, inv_keep);
+        if (m < p.M && n < p.N) epilogue_row8<true>(p, zc, ze, m, n, x, b8, th, inv_keep, dseed);
     }
 }
 
@@ -505,7 +506,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                 }
                 if (EPI == PP_EPI_ACT) {
                     if (saved) {
-                        auxv[a][ch] = act_fwd_grad_drop8(x, act, drop, p.drop_seed, (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
+                        auxv[a][ch] = act_fwd_grad_drop8(x, act, drop, smx_dseed(p.drop_p, p.drop_seed), (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
                     } else {
                         auxv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
                         act_fwd8(x, act);
@@ -525,7 +526,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                 }
                 if (drop && !saved) {
                     const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
-                    smx_drop_mul8(p.drop_seed, idx, th, inv_keep, x);        // idx % 8 == 0 (aligned views, N % 8 == 0)
+                    smx_drop_mul8(smx_dseed(p.drop_p, p.drop_seed), idx, th, inv_keep, x);        // (+ the step key: a scalar load on the dropout path only)
                 }
                 if (EPI == PP_EPI_LINEAR && has_res) {
                     const uint4 u = side[a][ch];

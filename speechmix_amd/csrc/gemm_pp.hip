@@ -337,3 +337,4 @@ extern "C" int smx_gemm_group(const SmxGemmParams* probs, int count, int dtype, 
     SMX_CHECK_LAUNCH();
 }
 
+SMX_STEP_KEY_TU(gemm_pp)

@@ -3,6 +3,7 @@
 // masking, element-wise adds.  All fp32 statistics; 16-B accesses where layouts allow.
 #include <cstdlib>
 #include "smx_common.h"
+#include <algorithm>
 
 // ---------------------------------------------------------------- cast fp32 -> T
 template <typename T>
@@ -628,7 +629,7 @@ extern "C" int smx_zero_ranges(float* base, const long long* table, int n, hipSt
 template <typename T>
 __global__ void mask_rows_kernel(T* __restrict__ x, const int* __restrict__ rows, int nrows, const float* __restrict__ emb, int D) {
     const int r = blockIdx.x;
-    if (r >= nrows) return;
+    if (r >= nrows || rows[r] < 0) return;          // (negative: padding of a fixed-capacity row list - captured steps)
     T* dst = x + (long long)rows[r] * D;
     for (int c = threadIdx.x; c < D; c += blockDim.x) Cvt<T>::st(dst + c, emb[c]);
 }
@@ -644,7 +645,7 @@ extern "C" int smx_mask_rows(void* x, const int* rows, int nrows, const float* e
 template <typename T>
 __global__ void mask_rows_bwd_kernel(T* __restrict__ dx, const int* __restrict__ rows, int nrows, float* __restrict__ demb, int D) {
     const int r = blockIdx.x;
-    if (r >= nrows) return;
+    if (r >= nrows || rows[r] < 0) return;
     T* src = dx + (long long)rows[r] * D;
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
         if (demb) atomicAdd(demb + c, Cvt<T>::ld(src + c));
@@ -657,6 +658,41 @@ extern "C" int smx_mask_rows_bwd(void* dx, const int* rows, int nrows, float* de
     if (dtype == SMX_BF16) hipLaunchKernelGGL(mask_rows_bwd_kernel<bf16_t>, dim3(nrows), dim3(256), 0, stream, (bf16_t*)dx, rows, nrows, demb, D);
     else if (dtype == SMX_F32) hipLaunchKernelGGL(mask_rows_bwd_kernel<float>, dim3(nrows), dim3(256), 0, stream, (float*)dx, rows, nrows, demb, D);
     else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
+
+// ---------------------------------------------------------------- per-step dropout key (smx_common.h)
+// One launch rewrites the key word of every translation unit whose kernels hash dropout masks; stream-ordered, so a step's
+// kernels (eager or replayed from a captured graph) read the key that was set ahead of them.
+SMX_STEP_KEY_TU(misc)
+extern "C" int smx_step_key_addr_gemm(void**);
+extern "C" int smx_step_key_addr_gemm_pp(void**);
+extern "C" int smx_step_key_addr_gemm_fr(void**);
+extern "C" int smx_step_key_addr_norm(void**);
+extern "C" int smx_step_key_addr_attention(void**);
+struct SmxKeyAddrs { unsigned* a[8]; int n; };
+__global__ void set_step_key_kernel(SmxKeyAddrs t, unsigned key) {
+    if ((int)threadIdx.x < t.n) *t.a[threadIdx.x] = key;
+}
+extern "C" int smx_set_step_key(unsigned key, hipStream_t stream) {
+    (void)hipGetLastError();  // drop stale errors left by other runtime users
+    static SmxKeyAddrs tab[16];
+    static bool done[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -5;
+    dev &= 15;
+    if (!done[dev]) {          // (first call per device: must not happen inside a stream capture - the engine sets a key eagerly first)
+        int (*fns[])(void**) = {smx_step_key_addr_misc, smx_step_key_addr_gemm, smx_step_key_addr_gemm_pp, smx_step_key_addr_gemm_fr,
+                                smx_step_key_addr_norm, smx_step_key_addr_attention};
+        tab[dev].n = 0;
+        for (auto fn : fns) {
+            void* a = nullptr;
+            if (fn(&a) != SMX_OK || !a) return -5;
+            tab[dev].a[tab[dev].n++] = (unsigned*)a;
+        }
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(set_step_key_kernel, dim3(1), dim3(64), 0, stream, tab[dev], key);
     SMX_CHECK_LAUNCH();
 }
 
@@ -888,6 +924,7 @@ extern "C" int smx_axpy_dev(void* y, const void* x, const float* a, int idx, lon
 // ---------------------------------------------------------------- out = x * dropout_mask(seed) (elementwise, flat index)
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long long n, float p, unsigned seed) {
+    seed = smx_dseed(p, seed);        // + the step key (smx_common.h), read once
     const unsigned th = smx_thresh24(p);
     const float inv = 1.0f / (1.0f - p);
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -909,6 +946,7 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, lon
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_colsum_kernel(const T* __restrict__ x, T* __restrict__ out, float* __restrict__ ws,
                                                              int M, int N, int Np, float p, unsigned seed) {
+    seed = smx_dseed(p, seed);        // + the step key (smx_common.h), read once
     __shared__ float red[4][64][8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 8;
@@ -1030,6 +1068,24 @@ extern "C" double smx_probe_mfma(float* out, int blocks, int iters, hipStream_t 
 __global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n16) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+// dst[0 .. bytes) = src[0 .. bytes) as ONE kernel on `stream` (16-byte aligned pointers).  A replayed step moves its inputs and a
+// LayerDrop-dropped layer's pass-through with this instead of hipMemcpyAsync: the runtime's copy path put ~150 us of idle GPU
+// time in front of every copy (kernel trace, round 5).  src may be pinned host memory (read through the host mapping).
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long n16, int tail) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail)
+        reinterpret_cast<unsigned char*>(dst + n16)[threadIdx.x] = reinterpret_cast<const unsigned char*>(src + n16)[threadIdx.x];
+}
+extern "C" int smx_copy_bytes(const void* src, void* dst, long long bytes, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (bytes <= 0) return SMX_OK;
+    if (!src || !dst || (((size_t)src | (size_t)dst) & 15)) return SMX_EINVAL;
+    const long long n16 = bytes / 16;
+    const int blocks = (int)std::min<long long>(256 * 8, std::max<long long>(1, (n16 + 255) / 256));
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, n16, (int)(bytes & 15));
+    SMX_CHECK_LAUNCH();
 }
 extern "C" int smx_probe_copy(const void* src, void* dst, long long bytes, hipStream_t stream) {
     (void)hipGetLastError();

@@ -36,6 +36,7 @@ struct SmxNormParams {
 // loaded once per wave instead of once per row, and a wave's next row is requested while it finishes the current one.
 template <typename T>
 __global__ __launch_bounds__(256, LN_FWD_BLOCKS_PER_CU) void norm_fwd_kernel(SmxNormParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int lane = threadIdx.x & 63;
     float gm[LN_NCH][8], bt[LN_NCH][8];
 #pragma unroll
@@ -149,6 +150,7 @@ struct SmxNormBwdParams {
 // 32-register column accumulators from the latency-critical dx path.
 template <typename T, bool ACT>
 __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(SmxNormBwdParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
@@ -293,6 +295,8 @@ __global__ __launch_bounds__(256) void norm_bwd_param_kernel(SmxNormBwdParams p)
 // halve the registers a wave holds (more waves per SIMD to overlap the row reductions with the loads).
 template <typename T, bool ACT, int PR>
 __global__ __launch_bounds__(256, PR == 1 ? LN_BLOCKS_PER_CU : 1) void norm_bwd_fused_kernel(SmxNormBwdParams p) {
+    p.drop_seed = smx_dseed(p.drop_p, p.drop_seed);        // + the step key (smx_common.h), read once
+    p.drop2_seed = smx_dseed(p.drop2_p, p.drop2_seed);
     __shared__ float red[4][64][8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float invD = 1.0f / (float)p.D;
@@ -549,3 +553,5 @@ extern "C" int smx_norm_bwd_partial_rows(int M) { return ln_grid(M, ln_rows_per_
 // ABI self-description (checked by the ctypes binding against its struct mirrors)
 extern "C" int smx_sizeof_SmxNormParams(void) { return (int)sizeof(SmxNormParams); }
 extern "C" int smx_sizeof_SmxNormBwdParams(void) { return (int)sizeof(SmxNormBwdParams); }
+
+SMX_STEP_KEY_TU(norm)

@@ -225,6 +225,28 @@ __device__ __forceinline__ void act_grad_mul8(float x[8], const float pre[8], in
     }
 }
 
+// ---- per-step dropout key (round 5) ----
+// A captured HIP graph bakes every kernel argument, dropout seeds included.  So that a replayed step still draws fresh masks, the
+// seed a kernel hashes with is (its argument + the STEP KEY), and the key is one device word per translation unit that
+// smx_set_step_key (misc.hip) rewrites once per training step - on the stream, ahead of the step's first kernel.  The word is 0
+// until somebody sets it: launches outside the keyed engine mode (tests that pin a mask to its seed) behave as before.
+// Kernels read it ONCE, on entry (smx_dseed), never inside a loop.
+// (one word per translation unit = per code object: the build passes -DSMX_TU=<file stem>, which makes the symbol's name unique -
+// a `static` device variable has no entry in the code object's symbol table, so hipGetSymbolAddress cannot find it)
+#ifndef SMX_TU
+#define SMX_TU anon
+#endif
+#define SMX_CAT2(a, b) a##b
+#define SMX_CAT(a, b) SMX_CAT2(a, b)
+#define SMX_KEYVAR SMX_CAT(smx_step_key_word_, SMX_TU)
+__device__ unsigned SMX_KEYVAR = 0u;
+__device__ __forceinline__ unsigned smx_dseed(float drop_p, unsigned seed) { return drop_p > 0.f ? seed + SMX_KEYVAR : seed; }
+// every translation unit whose kernels hash exports the address of its copy (collected by smx_set_step_key)
+#define SMX_STEP_KEY_TU(tag)                                                                                            \
+    extern "C" int smx_step_key_addr_##tag(void** out) {                                                                \
+        return hipGetSymbolAddress(out, HIP_SYMBOL(SMX_KEYVAR)) == hipSuccess ? SMX_OK : -5;                            \
+    }
+
 // ---- counter-based dropout: keep(idx) is a pure function of (seed, element index), so backward regenerates
 // the forward mask instead of storing it (TF: nn.functional.dropout sites listed in engine.py) ----
 // 32-bit integer mixes are quarter-rate on the vector unit (v_mul_lo_u32), and the GEMM epilogues hash every output element

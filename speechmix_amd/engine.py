@@ -123,6 +123,12 @@ def compute_mask_indices(shape, mask_prob, mask_length, rng, lengths=None, min_m
     return mask
 
 
+def site_seed(name, n=0):
+    """The fixed 32-bit dropout seed of a named site (keyed mode, Engine._dp): crc32 of the name, never 0."""
+    import zlib
+    return (zlib.crc32(f"{name}#{n}".encode()) & 0xffffffff) or 1
+
+
 class Engine:
     def __init__(self, store: FlatStore, enc_cfg: SpeechEncoderConfig, lm_cfg: LMConfig, dtype: int,
                  num_speech_layers: int, down_scale: int, enc_prefix="encoder_model.", lm_prefix="decoder_model."):
@@ -144,9 +150,49 @@ class Engine:
         self.stage_cb = None      # callable(stage_name): gradient ranges of that stage are final (dist.GradReducer)
         self.lm_adapters = store.has_prefix("adapters.")      # SpeechMixAdapter: bottleneck adapters behind every LM layer
 
-    def _dp(self, p):
-        """(p, fresh 32-bit seed) for one dropout site, or None when the site is inactive."""
-        return (float(p), int(self.drop_rng.integers(1, 2 ** 32 - 1))) if p and p > 0 else None
+    # ------------------------------------------------------------------ dropout seeds and the step key (round 5)
+    # Rounds 1-4 drew a fresh 32-bit seed per dropout site per step and passed it as a kernel argument - which a captured HIP
+    # graph would bake.  Now (SMX_STEP_KEY=0: the old scheme) a site's seed is a FIXED function of its name
+    # ("enc3/attn", "lmd0/o", ...) and what changes from step to step is the library's step key, one device word that every
+    # hashing kernel adds to its seed (csrc/smx_common.h smx_dseed): `begin_pass` draws the key from `drop_rng` (one draw per
+    # forward pass) and sets it on the stream ahead of the pass; backward re-sets it only if another pass has set a different
+    # key in between (two models alternating).  Eager and graph-replayed steps with the same key draw the same masks.
+    def keyed(self):
+        return self.dev.type == "cuda" and os.environ.get("SMX_STEP_KEY", "1") != "0"
+
+    def begin_pass(self, training=True):
+        """A new forward pass begins (one per model.forward / StepRunner micro-step): in training mode it gets a fresh step key
+        (or the one `pregen_attention_masks` already set for it).  -> the key, or None (unkeyed mode / eval)."""
+        self._scope, self._site_seen = "", {}
+        if not training or not self.keyed():
+            self._key = None
+            return None
+        if self._cap is not None:                  # capture pass: site seeds do not depend on the key, and the replay sets it
+            self._key = 1
+            return 1
+        k = getattr(self, "_preset_key", None)
+        self._preset_key = None
+        if k is None:
+            k = int(self.drop_rng.integers(1, 2 ** 32 - 1))
+        self._key = k
+        self._ensure_key(k)
+        return k
+
+    def _ensure_key(self, key):
+        if self._cap is None and key is not None and ops.CURRENT_KEY.get(self.dev.index) != key:
+            ops.set_step_key(key, self.dev.index)
+
+    def _dp(self, p, site=""):
+        """(p, 32-bit seed) for one dropout site, or None when the site is inactive.  site: the site's name inside the current
+        scope (`self._scope`); keyed mode derives the seed from it, the old scheme draws a fresh one."""
+        if not (p and p > 0):
+            return None
+        if getattr(self, "_key", None) is None:
+            return (float(p), int(self.drop_rng.integers(1, 2 ** 32 - 1)))
+        name = f"{self._scope}/{site}"
+        n = self._site_seen.get(name, 0)              # (a name met twice in one pass - a second LM pass - gets its own seed)
+        self._site_seen[name] = n + 1
+        return (float(p), site_seed(name, n))
 
     def _dropped(self, dy, drop, n, bias_grad=None, N=0):
         """dy * (the forward mask of a dropout site): gradient entering the dropped branch.  bias_grad [N]: also accumulate
@@ -172,6 +218,24 @@ class Engine:
             f = self._folds = None if os.environ.get("SMX_DEFER_FOLDS") == "0" else ops.FoldQueue()
         return f
 
+    # ------------------------------------------------------------------ HIP-graph capture of a whole step (graphs.py, round 5)
+    # `self._cap` is a graphs.StepGraphs while ITS capture pass runs this engine's forward / backward under stream capture, else
+    # None.  The pass closes one graph and opens the next at every `_seg` call (the places where a replayed step must be able to
+    # do something else: skip a LayerDrop-dropped layer, hand a finished stage to the gradient reducer), takes no host-RNG draws
+    # (every layer kept; SpecAugment rows come from a fixed-capacity device list that the replay refills) and sets no step key
+    # (the replay sets it, ahead of the first graph).
+    _cap = None
+
+    def _seg(self, closed, **carry):
+        """Boundary between two graphs of a captured step: `closed` names the graph that ends here; carry: tensors a replay may
+        need by name (a layer's input / output for the LayerDrop copy)."""
+        if self._cap is not None:
+            self._cap.boundary(closed, carry)
+
+    def _note(self, **carry):
+        if self._cap is not None:
+            self._cap.note(carry)
+
     def mark(self, name):
         """Stage boundary marker: with `self.marks` set to a list, records (name, HIP event on the current stream)."""
         marks = getattr(self, "marks", None)
@@ -188,11 +252,14 @@ class Engine:
             ops.GEMM_CONCURRENT = False
         if self.folds is not None:
             self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
-        if self.stage_cb is not None:
+        if self.stage_cb is not None or self._cap is not None:
             sr = getattr(self, "stage_ranges", None)
             if sr:
                 self._zero_fresh_within(sr.get(name))
-            self.stage_cb(name)
+            if self._cap is not None:
+                self._seg("stage:" + name)          # (the replay calls stage_cb between the graphs)
+            else:
+                self.stage_cb(name)
 
     # ------------------------------------------------------------------ gradient zeroing (round 4)
     # `optimizer.zero_grad()` + accumulate-into-zeros costs a 942-MB fill per step and a read of every weight gradient's old
@@ -216,24 +283,36 @@ class Engine:
         if store is None:
             store = self._gstore = {}            # offset -> [numel, consecutive steps without a write]
             self._gplan = None
-        if self._gplan is None:
-            # complement of the store ranges in [0, total), cut into rows of <= 65536 elements
-            rows, pos = [], 0
-            for off in sorted(store):
-                if off > pos:
-                    rows.append((pos, off - pos))
-                pos = max(pos, off + store[off][0])
-            if pos < st.total:
-                rows.append((pos, st.total - pos))
-            tab = []
-            for a, n in rows:
-                for c in range(0, n, 65536):
-                    tab.append((a + c, min(65536, n - c)))
-            self._gplan = (torch.tensor(tab, dtype=torch.int64).to(self.dev) if tab else None, len(tab))
+        self._ensure_gplan()
         tab, n = self._gplan
         if n:
             ops.zero_ranges(st.grad, tab, n)
         self._gfresh = {off: v[0] for off, v in store.items()}
+
+    def _ensure_gplan(self):
+        """The device table of the step's zeroing launch: the complement of the store ranges in [0, total), cut into rows of
+        <= 65536 elements (rebuilt when the store set changed; graphs.StepGraphs builds it ahead of its capture)."""
+        st = self.st
+        store = getattr(self, "_gstore", None)
+        if store is None:
+            store = self._gstore = {}
+            self._gplan = None
+        if getattr(self, "_gplan", None) is not None:
+            return
+        if self._cap is not None:
+            raise ops.CaptureAbort("the gradient-zeroing plan changed inside the capture pass")
+        rows, pos = [], 0
+        for off in sorted(store):
+            if off > pos:
+                rows.append((pos, off - pos))
+            pos = max(pos, off + store[off][0])
+        if pos < st.total:
+            rows.append((pos, st.total - pos))
+        tab = []
+        for a, n in rows:
+            for c in range(0, n, 65536):
+                tab.append((a + c, min(65536, n - c)))
+        self._gplan = (torch.tensor(tab, dtype=torch.int64).to(self.dev) if tab else None, len(tab))
 
     def _gacc(self, out):
         """-> True when a weight-gradient write into `out` must ADD to what is there, False when it is the step's first write
@@ -274,7 +353,9 @@ class Engine:
         fresh = getattr(self, "_gfresh", None)
         if not fresh or not ranges:
             return
-        for off in [o for o, m in fresh.items() if any(a <= o and o + m <= b for a, b in ranges)]:
+        # overlap, not containment: dist.stage_ranges cuts a stage's span into chunks mid-tensor, and a tensor that straddles a cut
+        # must still contribute zeros (not last step's gradient) to BOTH chunks' collectives
+        for off in [o for o, m in fresh.items() if any(o < b and a < o + m for a, b in ranges)]:
             self.st.grad[off:off + fresh[off]].zero_()
             self._gzeroed.add(off)
             del fresh[off]
@@ -509,6 +590,13 @@ class Engine:
             if gb is not None:
                 ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
             return
+        dq = getattr(self, "_wg_defer", None)
+        if dq is not None:
+            # deferred to the end of the layer (lm_bwd -> _wg_defer_flush): ONE fork to the second stream per layer instead of one
+            # per weight gradient.  In a captured step every fork moves the main chain to another hardware queue, and a
+            # cross-queue dependency costs ~8 us of idle GPU (kernel trace, round 5)
+            dq.append((dy, x, gw, N, K, M, av, bv, alpha, gb, dy_ld, kw))
+            return
         # LM stage (SMX_LM_WGRAD_STREAM=0: off): a weight gradient needs nothing that is still being computed, so it runs on a
         # second stream beside the small-grid kernels of the LM's backward (decoder: 48 workgroups per launch, text encoder:
         # 1.5 per CU) and is joined at the end of the stage.  What keeps that safe: dy and x are never written again (every
@@ -525,6 +613,28 @@ class Engine:
                 ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
         dy.record_stream(side)
         x.record_stream(side)
+
+    def _wg_defer_begin(self):
+        on = getattr(self, "_side_active", False) and (self._cap is not None or os.environ.get("SMX_LM_WGRAD_DEFER", "auto") == "1") \
+            and os.environ.get("SMX_LM_WGRAD_DEFER", "auto") != "0"
+        self._wg_defer = [] if on else None
+
+    def _wg_defer_flush(self):
+        dq, self._wg_defer = getattr(self, "_wg_defer", None), None
+        if not dq:
+            return
+        side = self._side
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for dy, x, gw, N, K, M, av, bv, alpha, gb, dy_ld, kw in dq:
+                self._wgrad_gemm(dy, x, gw, N, K, M, av, bv, alpha, True, **kw)
+                if gb is not None:
+                    ops.colsum(dy, gb, M, N, dy_ld or N, self.dt, alpha, folds=self.folds)
+        for dy, x, *_ in dq:
+            dy.record_stream(side)
+            x.record_stream(side)
 
     # Grouped weight gradients (SMX_WGRAD_GROUP=0: off).  Launched one by one, each of an encoder layer's four weight
     # gradients has 9-36 output tiles of 256 x 256 and needs 7 K slices to fill the chip: 7 fp32 slabs written and read back
@@ -795,11 +905,11 @@ class Engine:
         scale = scale if scale is not None else (d // H) ** -0.5
         sv = {}
         ph, pa, pf = drop if drop is not None else (0.0, 0.0, 0.0)
-        sv["d_o"], sv["d_xo"] = self._dp(ph), (self._dp(ph) if enc is not None else None)
-        d_act, d_out = self._dp(pf), self._dp(ph)
-        da, dxa = self._dp(pa), (self._dp(pa) if enc is not None else None)
+        sv["d_o"], sv["d_xo"] = self._dp(ph, "o"), (self._dp(ph, "xo") if enc is not None else None)
+        d_act, d_out = self._dp(pf, "act"), self._dp(ph, "out")
+        da, dxa = self._dp(pa, "attn"), (self._dp(pa, "xattn") if enc is not None else None)
         amask = None
-        if premask is not None and da is not None and premask["p"] == da[0]:
+        if premask is not None and da is not None and premask["p"] == da[0] and premask.get("key") == getattr(self, "_key", None):
             da, amask = (da[0], premask["seed"]), premask["masks"]      # the bit matrices generated beside the last optimizer step
         if not pre_ln:
             o, sv["a"] = self.attn_fwd(x, None, B, T, T, d, H, nm["attn"], causal, scale, bias, drop=da, klen=klen, masks=amask)
@@ -1151,8 +1261,10 @@ class Engine:
                 # blocked weight gradient [G][J Cg][K'] = dY^T X over the B Tb rows (frame j of row t' sits K - 1 - P + J t' + j frames
                 # into dyg), then its J shifted diagonals folded into the forward-pack layout
                 nJ = J * Cg * Kp
-                cands = [(1, 1), (1, 2), (1, 4), (8, 1), (8, 2)]
-                key = ("posconv_wgrad", self.dt, B, T, G, Cg, K, J)
+                # (the one-workgroup-per-CU kernel only where the backward policy allows it - ops.pp_allowed - and the CU budget in
+                # the key, like _wgrad_gemm / _choose_mode: a pick made on one GPU must not be reused beside RCCL)
+                cands = [(1, 1), (1, 2), (1, 4)] + ([(8, 1), (8, 2)] if ops.pp_allowed() else [])
+                key = ("posconv_wgrad", self.dt, B, T, G, Cg, K, J, ops.pp_cus())
                 pick = ops._tuned_get(key)
                 if isinstance(pick, list):
                     pick = tuple(pick)
@@ -1205,23 +1317,28 @@ class Engine:
         return dh
 
     # ------------------------------------------------------------------ SpecAugment indices (host RNG)
-    def _spec_augment_rows(self, B, T, lengths=None):
+    def _spec_augment_rows(self, B, T, lengths=None, host_only=False):
         """Flat row indices (b * T + t) of the frames HF's `_mask_hidden_states` replaces with `masked_spec_embed`
         (TF:models/wav2vec2/modeling_wav2vec2.py:1074-1119), or None."""
         ec = self.ec
         if getattr(ec, "mask_feature_prob", 0.0) > 0:
             raise NotImplementedError("mask_feature_prob > 0 (SpecAugment along the feature axis) is not built; the reference's "
                                       "checkpoints ship 0.0")
+        if self._cap is not None:
+            # fixed-capacity device list (negative = unused), refilled per replay
+            return self._cap.spec_rows(self, B, T) if (ec.mask_time_prob > 0 and lengths is None) else None
         rec = getattr(self.host_rng, "mask", None)
         if rec is not None:
             mask = rec
         else:
             if ec.mask_time_prob <= 0:
-                return None
+                return np.zeros(0, dtype=np.int32) if host_only else None
             mask = compute_mask_indices((B, T), ec.mask_time_prob, ec.mask_time_length, self.host_rng, lengths,
                                         ec.mask_time_min_masks)
         self.last_spec_mask = mask
         rows = np.flatnonzero(mask.reshape(-1))
+        if host_only:
+            return rows.astype(np.int32)
         if rows.size == 0:
             return None
         return self.h2d(rows.astype(np.int32))
@@ -1244,21 +1361,30 @@ class Engine:
         st = getattr(self, "_mask_stream", None)
         if st is None:
             st = self._mask_stream = torch.cuda.Stream()
-        old = getattr(self, "_premask", None) or {}
+        bufs = self._persist.setdefault("_premask_bufs", {})      # (B, T, layer) -> pair: the SAME buffers whenever the shape returns
+        # keyed mode: the NEXT pass's step key is drawn and set now (on the main stream, behind this step's backward and ahead of
+        # the event the mask stream waits for); the masks are hashed with the sites' fixed seeds + that key
+        key = None
+        if self.keyed():
+            key = self._preset_key = int(self.drop_rng.integers(1, 2 ** 32 - 1))
+            ops.set_step_key(key, self.dev.index)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())          # behind the backward that still reads the previous pairs
         st.wait_event(ev)
-        new = dict(B=B, T=T, layers={})
+        new = dict(B=B, T=T, layers={}, key=key)
         with torch.cuda.stream(st):
             for i in range(self.L):
-                seed = int(self.drop_rng.integers(1, 2 ** 32 - 1))
-                prev = (old.get("layers") or {}).get(i)
+                seed = site_seed(f"enc{i}/attn") if key is not None else int(self.drop_rng.integers(1, 2 ** 32 - 1))
                 masks = ops.attn_dropout_masks(B, ec.num_attention_heads, T, T, 64, p, seed, self.dt, self.dev,
-                                               reuse=prev["masks"] if prev else None)
+                                               reuse=bufs.get((B, T, i)))
                 if masks is None:
                     self._premask = None
                     return
-                new["layers"][i] = dict(p=p, seed=seed, masks=masks)
+                bufs[(B, T, i)] = masks
+                if len(bufs) > 4 * self.L:                # (a few shapes at most: ragged training sets fall back to in-place masks)
+                    for k in [k for k in bufs if k[:2] != (B, T)]:
+                        del bufs[k]
+                new["layers"][i] = dict(p=p, seed=seed, masks=masks, key=key)
             new["ev"] = torch.cuda.Event()
             new["ev"].record(st)
         self._premask = new
@@ -1267,6 +1393,11 @@ class Engine:
         pm = getattr(self, "_premask", None)
         if pm is None or pm["B"] != B or pm["T"] != T:
             return None
+        if self._cap is not None:
+            # capture pass: the layer's graph reads the pair's (static, reused) buffers; the replay waits for the generation
+            # itself and checks nothing - every replayed step is preceded by a pregen with the step's key
+            e = pm["layers"].get(i)
+            return dict(e, key=self._key) if e is not None else None
         if pm.get("ev") is not None:                     # first use in this forward: the main stream waits for the generation
             torch.cuda.current_stream().wait_event(pm["ev"])
             pm["ev"] = None
@@ -1304,7 +1435,8 @@ class Engine:
         else:
             fn = feat
         sv["fp_in"] = fn
-        sv["d_fp"] = self._dp(ec.feat_proj_dropout) if training else None      # TF:...wav2vec2.py:429-434
+        self._scope = "front"
+        sv["d_fp"] = self._dp(ec.feat_proj_dropout, "fp") if training else None      # TF:...wav2vec2.py:429-434
         h = self.lin(fn, self.W(ep + "feature_projection.projection.weight"), self.P(ep + "feature_projection.projection.bias"),
                      M, d, C, drop=sv["d_fp"])
         sv["mask_rows"] = None
@@ -1321,7 +1453,7 @@ class Engine:
             sv["pad_rows"] = pad_rows
         s, sv["pc"] = self.posconv_fwd(h, B, T)
         stable = ec.do_stable_layer_norm
-        d_in = self._dp(ec.hidden_dropout) if training else None                # TF:...wav2vec2.py:700-703 / 786-788
+        d_in = self._dp(ec.hidden_dropout, "in") if training else None                # TF:...wav2vec2.py:700-703 / 786-788
         sv["d_in"] = d_in
         if not stable:
             x, sv["enc_ln"] = self.ln_fwd(s, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps,
@@ -1333,19 +1465,24 @@ class Engine:
         sv["layers"] = []
         hidden = [x]
         for i in range(self.L):
+            self._seg("front" if i == 0 else f"enc_fwd{i - 1}")
+            self._note(**{f"fwd_in{i}": x})
             # TF:...wav2vec2.py:709-723: one draw per layer - HF draws in eval mode too (`torch.rand([])` precedes `self.training and`),
             # so the draw is unconditional here as well; only train-mode draws decide anything
-            draw = self.host_rng.layerdrop()
+            draw = self.host_rng.layerdrop() if self._cap is None else 2.0
             if training and draw < ec.layerdrop:
                 sv["layers"].append(None)
                 hidden.append(x)
                 continue
             ops.GEMM_TAG = "enc_layer"
+            self._scope = f"enc{i}"
             x, lsv = self.layer_fwd(x, B, T, d, ec.num_attention_heads, ec.intermediate_size, self._w2v2_layer_names(i),
                                     stable, act, eps, drop=drop, klen=klen, premask=self._take_premask(i, B, T))
             ops.GEMM_TAG = None
             sv["layers"].append(lsv)
             hidden.append(x)
+            self._note(**{f"fwd_out{i}": x})
+        self._seg(f"enc_fwd{self.L - 1}" if self.L else "front")
         if stable:
             x, sv["final_ln"] = self.ln_fwd(x, ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d, eps)
             hidden[-1] = x
@@ -1370,7 +1507,9 @@ class Engine:
         if stable:
             dx = self.ln_bwd(dx, sv["final_ln"], ep + "encoder.layer_norm.weight", ep + "encoder.layer_norm.bias", M, d)
         pending = None          # stage whose grouped weight gradients are still running on the second stream
+        self._seg("pre_layers")
         for i in range(self.L - 1, -1, -1):
+            self._note(**{f"bwd_in{i}": dx})
             if sv["layers"][i] is not None:
                 ops.GEMM_TAG = "enc_layer"
                 self._wg_begin()
@@ -1392,6 +1531,7 @@ class Engine:
                 pending = None
             if ws is not None:
                 ops.axpy_dev(dx, ws[0], ws[1], i, M * d, False, self.dt)
+            self._note(**{f"bwd_out{i}": dx})
             self._stage(f"enc_layer{i}")
         if pending is not None:
             self._join_wg(pending)
@@ -1496,6 +1636,10 @@ class Engine:
         lc = self.lc
         name = f"{self.lp}{side}.block.0.layer.0.SelfAttention.relative_attention_bias.weight"
         nb, md = lc.relative_attention_num_buckets, lc.relative_attention_max_distance
+        ck = ("_t5_buckets", side, Tq, Tk)
+        if ck in self._persist:                     # (cached on the device: no host-to-device copy inside a step)
+            buckets = self._persist[ck]
+            return self.P(name)[buckets].permute(2, 0, 1).contiguous(), buckets
         ctx = torch.arange(Tq)[:, None]
         mem = torch.arange(Tk)[None, :]
         rel = mem - ctx
@@ -1512,7 +1656,7 @@ class Engine:
         small = rel < max_exact
         large = max_exact + (torch.log(rel.float() / max_exact) / math.log(md / max_exact) * (n - max_exact)).long()
         large = torch.min(large, torch.full_like(large, n - 1))
-        buckets = (ret + torch.where(small, rel, large)).to(self.dev)
+        buckets = self._persist[ck] = (ret + torch.where(small, rel, large)).to(self.dev)
         table = self.P(name)                                   # [buckets, H] fp32
         return table[buckets].permute(2, 0, 1).contiguous(), buckets
 
@@ -1554,7 +1698,8 @@ class Engine:
         t5 = lc.model_type == "t5"
         pre_ln = lc.model_type in ("mbart", "t5")
         act = _act_id(lc.activation_function)
-        sv = dict(B=B, S=S, Ld=Ld, t5=t5)
+        sv = dict(B=B, S=S, Ld=Ld, t5=t5, key=getattr(self, "_key", None) if training else None)
+        self._scope = "lm"
         emb_name = lp + ("shared.weight" if t5 else "model.shared.weight")
         escale = math.sqrt(d) if (lc.scale_embedding and not t5) else 1.0
         sv["emb_name"], sv["escale"] = emb_name, escale
@@ -1578,7 +1723,7 @@ class Engine:
             ebias, eb = self._t5_bias("encoder", S, S)
             dbias, db = self._t5_bias("decoder", Ld, Ld)
             sv["t5_buckets"] = (eb, db)
-            sv["d_enc_in"] = self._dp(pdrop)
+            sv["d_enc_in"] = self._dp(pdrop, "enc_in")
             h = self._dropped(x, sv["d_enc_in"], B * S * d)
             eps = lc.layer_norm_epsilon
         else:
@@ -1587,18 +1732,20 @@ class Engine:
             self._check_positions(S, Ld)
             h, sv["enc_emb_ln"] = self.ln_fwd(x, pe + "layernorm_embedding.weight", pe + "layernorm_embedding.bias", B * S, d,
                                               eps, pos=self.W(pe + "embed_positions.weight"), pos_period=S, pos_offset=2,
-                                              want_sum=True, drop=self._dp(pdrop))
+                                              want_sum=True, drop=self._dp(pdrop, "enc_emb"))
         sv["enc_layers"] = []
         for i in range(lc.encoder_layers):
             nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
+            self._scope = f"lme{i}"
             h, lsv = self.layer_fwd(h, B, S, d, H, F, nm, pre_ln, act, eps, scale=1.0 if t5 else None, rms=t5, bias=ebias,
                                     drop=drop, klen=enc_klen)
             if self.lm_adapters:
                 h, lsv["adapter"] = self.adapter_fwd(h, i, B * S, d)
             sv["enc_layers"].append(lsv)
+        self._scope = "lm"
         if t5:
             h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "encoder.final_layer_norm.weight", None, B * S, d, eps, rms=True,
-                                                drop=self._dp(pdrop))
+                                                drop=self._dp(pdrop, "enc_final"))
         elif lc.model_type == "mbart":
             h, sv["enc_final_ln"] = self.ln_fwd(h, lp + "model.encoder.layer_norm.weight", lp + "model.encoder.layer_norm.bias",
                                                 B * S, d, eps)
@@ -1613,21 +1760,23 @@ class Engine:
             pd = lp + "model.decoder."
             y, sv["dec_emb_ln"] = self.ln_fwd(y, pd + "layernorm_embedding.weight", pd + "layernorm_embedding.bias", B * Ld, d,
                                               eps, pos=self.W(pd + "embed_positions.weight"), pos_period=Ld, pos_offset=2,
-                                              want_sum=True, drop=self._dp(pdrop))
+                                              want_sum=True, drop=self._dp(pdrop, "dec_emb"))
         else:
-            sv["d_dec_in"] = self._dp(pdrop)
+            sv["d_dec_in"] = self._dp(pdrop, "dec_in")
             y = self._dropped(y, sv["d_dec_in"], B * Ld * d)
         sv["dec_layers"] = []
         for i in range(lc.decoder_layers):
             nm = self._t5_layer_names("decoder", i) if t5 else self._bart_layer_names("decoder", i)
+            self._scope = f"lmd{i}"
             y, lsv = self.layer_fwd(y, B, Ld, d, Hd, Fd, nm, pre_ln, act, eps, causal=True, scale=1.0 if t5 else None,
                                     enc=enc, Tk=S, rms=t5, bias=dbias, drop=drop, enc_klen=enc_klen)
             if self.lm_adapters:
                 y, lsv["adapter"] = self.adapter_fwd(y, lc.encoder_layers + i, B * Ld, d)
             sv["dec_layers"].append(lsv)
+        self._scope = "lm"
         if t5:
             y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "decoder.final_layer_norm.weight", None, B * Ld, d, eps, rms=True,
-                                                drop=self._dp(pdrop))
+                                                drop=self._dp(pdrop, "dec_final"))
         elif lc.model_type == "mbart":
             y, sv["dec_final_ln"] = self.ln_fwd(y, lp + "model.decoder.layer_norm.weight", lp + "model.decoder.layer_norm.bias",
                                                 B * Ld, d, eps)
@@ -1933,6 +2082,7 @@ class Engine:
         Md, Ms = B * Ld, B * S
         emb_name, escale = sv["emb_name"], sv["escale"]
         lm_trainable = self.tr(head)
+        self._ensure_key(sv.get("key"))
         dy = self.new(Md, d)
         if isinstance(dlogits, str):             # streamed head (lm_losses): recompute each chunk's logits, then its three products
             R = self.head_chunk_rows(Md, Vp)
@@ -1984,10 +2134,12 @@ class Engine:
             side = self._side if getattr(self, "_side_active", False) else None
             if side is not None:
                 self._wg_begin(rows=Md)
+            self._wg_defer_begin()
             dy = self.layer_bwd(dy, sv["dec_layers"][i], nm, pre_ln, act, rms=t5, denc=denc,
                                 dbias=tb["decoder"][1] if "decoder" in tb else None)
             if side is not None:
                 self._wg_flush(side=side)
+            self._wg_defer_flush()
             denc[1] = False
         if "decoder" in tb:
             self._t5_bias_bwd(tb["decoder"], sv["t5_buckets"][1])
@@ -2016,8 +2168,10 @@ class Engine:
             nm = self._t5_layer_names("encoder", i) if t5 else self._bart_layer_names("encoder", i)
             if "adapter" in sv["enc_layers"][i]:
                 dh = self.adapter_bwd(dh, sv["enc_layers"][i]["adapter"], i, Ms, d)
+            self._wg_defer_begin()
             dh = self.layer_bwd(dh, sv["enc_layers"][i], nm, pre_ln, act, rms=t5,
                                 dbias=tb["encoder"][1] if "encoder" in tb else None)
+            self._wg_defer_flush()
         if "encoder" in tb:
             self._t5_bias_bwd(tb["encoder"], sv["t5_buckets"][0])
         if not t5:
@@ -2116,7 +2270,7 @@ class Engine:
             # concatenation along time is pure data movement
             e = torch.cat((pe.view(1, P, dd).expand(B, P, dd), e.view(B, S, dd)), 1).contiguous().view(B * (P + S), dd)
             S = S + P
-        state = dict(speech=ssv, bridge=bsv, B=B, ws=ws, P=P, prompt_ids=prompt_ids)
+        state = dict(speech=ssv, bridge=bsv, B=B, ws=ws, P=P, prompt_ids=prompt_ids, key=getattr(self, "_key", None) if training else None)
         lm_lengths = None
         if ssv.get("frame_len") is not None:
             lm_lengths = []
@@ -2129,6 +2283,7 @@ class Engine:
 
     def speech_side_bwd(self, de, sv):
         """de: gradient wrt inputs_embeds [B*S, d_lm] (prompt rows included) -> all gradients ahead of the LM."""
+        self._ensure_key(sv.get("key"))
         P = sv.get("P", 0)
         if P:
             lc, B = self.lc, sv["B"]
@@ -2165,6 +2320,7 @@ class Engine:
         self.st.refresh_shadow()
         B = wave.shape[0]
         Ld = dec_ids.shape[1]
+        self.begin_pass(training or bool(lm_training))
         e, S, state, ex = self.speech_side_fwd(wave, training, prompt_ids, weighted_sum, sample_lengths)
         self.mark("fwd:bridge")
         # sample_lengths: the speech encoder's padding mask; lm_mask: also mask the padded positions as LM-encoder keys (what HF's

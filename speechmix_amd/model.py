@@ -491,6 +491,7 @@ class SpeechMixEED(nn.Module):
             # a stand-alone `decoder_model(...)` / `cal_loss(...)` call (text-only LM loops): its own step, so that the first
             # backward node after an `optimizer.zero_grad()` zeroes the flat gradient instead of adding to the last call's
             self._step_token += 1
+            self.engine.begin_pass(self.training and self.decoder_model.training)          # (a fresh dropout step key: Engine.begin_pass)
         lm_trainable = any(p.requires_grad for p in self.decoder_model.parameters())
         emb_grad = inputs_embeds is not None and inputs_embeds.requires_grad
         if not (torch.is_grad_enabled() and (lm_trainable or emb_grad)):
@@ -633,6 +634,7 @@ class SpeechMixEED(nn.Module):
         if not getattr(type(self).cal_loss, "_smx_builtin", False):
             if sample_lengths is not None:
                 raise NotImplementedError("attention_mask with an overridden cal_loss: pass the LM mask to decoder_model(...) yourself")
+            self.engine.begin_pass(self.training)          # (a fresh dropout step key for this pass; Engine.forward draws its own)
             e = _SpeechFn.apply(self, wave, training, prompt_ids, self._anchor)
             if not torch.is_grad_enabled():
                 e = e.detach()

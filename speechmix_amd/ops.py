@@ -19,17 +19,13 @@ def torch_dtype(dt):
     return _TORCH_DT[dt]
 
 
-_DEV_INDEX = None
-
-
 def _stream():
-    """Raw handle of PyTorch's CURRENT stream on this process's device.  `torch.cuda.current_stream().cuda_stream` costs ~8 us of
-    Python per call (device-index normalisation, a Stream object) - 7 ms of host time per training step at ~830 launches, where
-    the host enqueues only ~1.4 x faster than the GPU executes; the C accessor is the same value in ~0.3 us."""
-    global _DEV_INDEX
-    if _DEV_INDEX is None:
-        _DEV_INDEX = torch.cuda.current_device()         # one process per GPU: fixed for the life of the process
-    return C.c_void_p(torch._C._cuda_getCurrentRawStream(_DEV_INDEX))
+    """Raw handle of PyTorch's CURRENT stream on the CURRENT device.  `torch.cuda.current_stream().cuda_stream` costs ~8 us of
+    Python per call (device-index normalisation, a Stream object) - 7 ms of host time per training step at ~830 launches; the two
+    C accessors return the same value in ~0.5 us.  The device is re-read on every call: a launch that precedes the rank's
+    `torch.cuda.set_device(local_rank)` (the reference's train.py builds the model before TrainingArguments / Trainer pick the
+    device) must not pin later launches to device 0's stream."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):
@@ -223,12 +219,21 @@ def _launch(p, dtype):
 TUNE_ROUNDS = int(os.environ.get("SMX_TUNE_ROUNDS", "5"))
 
 
+CAPTURING = False        # a graphs.StepGraphs capture pass is running: nothing may synchronise or time
+
+
+class CaptureAbort(RuntimeError):
+    """Raised when something that cannot be captured (live tuning, a host-to-device copy) is met during a capture pass."""
+
+
 def measure_candidates(runs, rounds=None, reps=2):
     """Live timing of alternative launches of ONE piece of work: runs = {candidate: callable that enqueues it}.  Every candidate
     is warmed once, then `rounds` interleaved rounds time `reps` back-to-back launches of each; a candidate's figure is the
     MEDIAN of its samples after dropping those above twice its fastest (the ~1.8-ms single-launch outliers of this pool,
     DESIGN.md 6b).  A candidate whose launch raises RuntimeError (a class the variant is not instantiated for) is left out.
     -> {candidate: milliseconds per launch}."""
+    if CAPTURING:
+        raise CaptureAbort("a kernel pick is missing (live tuning cannot run inside a stream capture)")
     rounds = rounds or TUNE_ROUNDS
     ok = []
     for c, run in runs.items():
@@ -1114,6 +1119,27 @@ def weighted_sum_bwd(hidden, w, dy, dots, dw, sw, n, dtype):
 def axpy_dev(y, x, a, idx, n, init, dtype):
     L.check(L.lib().smx_axpy_dev(C.c_void_p(_ptr(y)), C.c_void_p(_ptr(x)), C.c_void_p(_ptr(a)), idx, C.c_longlong(n),
                                  int(init), dtype, _stream()), "smx_axpy_dev")
+
+
+CURRENT_KEY = {}         # device index -> the step key last set on it by this process (None: never set = 0 in the library)
+
+
+def set_step_key(key, device_index=None):
+    """The library's step key (csrc/smx_common.h): every kernel that hashes a dropout mask uses (its seed argument + key).
+    Stream-ordered on the CURRENT stream; 0 restores the plain-seed behaviour."""
+    if device_index is None:
+        device_index = torch._C._cuda_getDevice()
+    L.check(L.lib().smx_set_step_key(C.c_uint(int(key) & 0xffffffff), _stream()), "smx_set_step_key")
+    CURRENT_KEY[device_index] = int(key) & 0xffffffff
+
+
+def copy_bytes(src, dst, nbytes=None):
+    """dst <- src (same byte count, contiguous, 16-byte aligned) as one kernel on the current stream; src may be a PINNED host
+    tensor.  The replayed step's copies (graphs.py): `Tensor.copy_` goes through hipMemcpyAsync, which costs ~150 us of idle GPU."""
+    n = src.numel() * src.element_size() if nbytes is None else nbytes
+    if not dst.is_cuda or not (src.is_cuda or src.is_pinned()):
+        raise RuntimeError("copy_bytes: device destination, device or pinned source")
+    L.check(L.lib().smx_copy_bytes(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_longlong(n), _stream()), "smx_copy_bytes")
 
 
 def dropout(x, out, n, p, seed, dtype):

@@ -96,6 +96,8 @@ class StepRunner:
             self._af_layer = [self.layer_of[nm] for nm in self.af_names]
         self._flags = None
         self._force_comm = force_comm
+        self.use_graphs = True           # (see _step_graphs)
+        self._graphs, self._graph_warm, self._graph_failures = None, {}, 0
         self._refresh_trainable()
         if self.world > 1 or force_comm:
             # RCCL runs beside backward: one-workgroup-per-CU kernels leave it CUs (ops.PP_BACKWARD_CUS)
@@ -120,6 +122,44 @@ class StepRunner:
         self.engine.stage_cb = self.reducer.stage_done
         self.engine.stage_ranges = self.reducer.stages        # (ranges a reported stage hands to the reducer: Engine._stage)
 
+    # ------------------------------------------------------------------ captured steps (graphs.py)
+    def _step_graphs(self, wave, dec_ids, labels, text, fwd_kw):
+        """-> the graphs.StepGraphs of this step's configuration, or None (eager).  A configuration - shapes, train / eval flags,
+        the requires_grad pattern - is captured once it has run `graphs.WARM_STEPS` eager steps in a row (kernel picks made, the
+        first-write gradient ranges learned); another configuration drops the captured one (one set of static activations at
+        a time: ~11 GB at config 2).  SMX_STEP_GRAPHS=0, gradient accumulation, live profiling (bench.py's instrumented pass,
+        stage marks) and weighted-sum models in train mode stay eager."""
+        from . import graphs
+        eng, st = self.engine, self.store
+        if (not graphs.ENABLED or not self.use_graphs or st.device.type != "cuda" or self.grad_accum != 1
+                or ops.GEMM_PROFILE is not None or ops.OP_PROFILE is not None or getattr(eng, "marks", None) is not None
+                or (fwd_kw["weighted_sum"] and fwd_kw["training"]) or self._graph_failures >= 2):
+            return None
+        key = (tuple(wave.shape), tuple(labels.shape), tuple(text.shape) if text is not None else None, bool(fwd_kw["training"]),
+               bool(fwd_kw["lm_training"]), self._flags, eng.dt, ops.PP_BACKWARD_CUS)
+        G = self._graphs
+        if G is not None and G.key != key:
+            G = self._graphs = None                    # another configuration: its static buffers go back to the allocator
+            self._graph_warm = {}
+        if G is not None:
+            return G
+        n = self._graph_warm.get(key, 0)
+        warm = max(graphs.WARM_STEPS, 5 if self.world > 1 else 0)       # (N > 1: past the pick broadcasts of steps 1 and 3)
+        if n < warm:
+            self._graph_warm = {key: n + 1}
+            return None
+        try:
+            G = graphs.StepGraphs(self, key).capture(wave, dec_ids.contiguous(), labels.contiguous(), text, fwd_kw)
+        except RuntimeError as e:          # (ops.CaptureAbort included) stay eager; a second failure disables capturing
+            import warnings
+            self._graph_failures += 1
+            self._graph_warm = {}
+            warnings.warn(f"StepRunner: HIP-graph capture of the step failed ({str(e)[:300]}); running eagerly")
+            self.engine.saved = None
+            return None
+        self._graphs = G
+        return G
+
     def current_lr(self):
         return float(self.lr(self.t)) if callable(self.lr) else float(self.lr)
 
@@ -143,15 +183,21 @@ class StepRunner:
             self._refresh_trainable()
             self.reducer.begin_step()
         text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
-        out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(),
-                          training=m.training and m.encoder_model.training, text_ids=text, weighted_sum=m.weighted_sum,
-                          lm_training=m._lm_training(), want_logits=False)
-        # micro-batches before the last only add their gradient (no stage reports: nothing is reduced or updated yet)
-        cb, eng.stage_cb = eng.stage_cb, (eng.stage_cb if last else None)
-        try:
-            eng.backward(gscale=1.0 / ga, zero_grads=first)
-        finally:
-            eng.stage_cb = cb
+        training = m.training and m.encoder_model.training
+        fwd_kw = dict(training=training, weighted_sum=m.weighted_sum, lm_training=m._lm_training(), want_logits=False)
+        G = self._step_graphs(wave, decoder_input_ids, labels, text, fwd_kw)
+        if G is not None:
+            # the whole forward + backward as a chain of captured HIP graphs (graphs.py): same kernels, same arguments
+            out = G.replay(wave, decoder_input_ids, labels, text)
+            out = dict(out, loss=out["loss"].clone())
+        else:
+            out = eng.forward(wave, decoder_input_ids.contiguous(), labels.contiguous(), text_ids=text, **fwd_kw)
+            # micro-batches before the last only add their gradient (no stage reports: nothing is reduced or updated yet)
+            cb, eng.stage_cb = eng.stage_cb, (eng.stage_cb if last else None)
+            try:
+                eng.backward(gscale=1.0 / ga, zero_grads=first)
+            finally:
+                eng.stage_cb = cb
         # LayerDrop: a layer is without a gradient for this update only if every micro-batch dropped it
         self._dropped_all = set(eng.last_dropped) if first else (self._dropped_all & set(eng.last_dropped))
         if not last:
