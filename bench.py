@@ -273,7 +273,8 @@ def main():
     setup_steps = 0
     from speechmix_amd import graphs as _graphs
     if _graphs.ENABLED:
-        while runner._graphs is None and runner._graph_failures < 2 and setup_steps < 8:
+        while (runner._graphs is None or runner._graph_trial is not None) and not runner._graph_choice \
+                and runner._graph_failures < 2 and setup_steps < 16:
             loss = runner.step(wave, labels)
             setup_steps += 1
     for _ in range(args.warmup):
@@ -331,7 +332,7 @@ def main():
     eval_ms = None
     if not args.eval_mode and not args.no_eval_leg:
         model.eval()
-        for _ in range(6 if _graphs.ENABLED else 2):          # (another configuration: its own eager steps + capture)
+        for _ in range(12 if _graphs.ENABLED else 2):         # (another configuration: its own eager steps, capture and trial)
             runner.step(wave, labels)
         if world > 1:
             dist.barrier()
@@ -366,7 +367,8 @@ def main():
                            "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
                 "final_loss": round(final_loss, 4),
                 "host": {"enqueue_ms_per_step": round(1e3 * host_elapsed / args.steps, 3),
-                         "step_graphs": runner._graphs is not None,
+                         "step_graphs": runner._graphs is not None, "step_graphs_mode": _graphs.MODE,
+                         "trial_fwd_bwd_ms": runner.graph_trial_ms,
                          "graphs_per_step": len(runner._graphs.graphs) if runner._graphs is not None else 0,
                          "setup_steps_before_warmup": setup_steps,
                          "note": "wall time of one StepRunner.step call on the host with an empty queue ahead of it (median of 5, outside "

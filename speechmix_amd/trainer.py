@@ -98,6 +98,7 @@ class StepRunner:
         self._force_comm = force_comm
         self.use_graphs = True           # (see _step_graphs)
         self._graphs, self._graph_warm, self._graph_failures = None, {}, 0
+        self._graph_trial, self._graph_choice, self.graph_trial_ms = None, {}, None
         self._refresh_trainable()
         if self.world > 1 or force_comm:
             # RCCL runs beside backward: one-workgroup-per-CU kernels leave it CUs (ops.PP_BACKWARD_CUS)
@@ -141,7 +142,20 @@ class StepRunner:
         if G is not None and G.key != key:
             G = self._graphs = None                    # another configuration: its static buffers go back to the allocator
             self._graph_warm = {}
+            self._graph_trial = None
+        if self._graph_choice.get(key) == "eager":     # (auto mode measured this configuration: eager was faster)
+            return None
         if G is not None:
+            tr = self._graph_trial
+            if tr is not None:                         # auto mode's trial: TRIAL_STEPS replayed, then TRIAL_STEPS eager, timed
+                if len(tr["replay"]) < graphs.TRIAL_STEPS:
+                    tr["now"] = "replay"
+                    return G
+                if len(tr["eager"]) < graphs.TRIAL_STEPS:
+                    tr["now"] = "eager"
+                    return None
+                self._graph_decide(key)
+                return self._graphs
             return G
         n = self._graph_warm.get(key, 0)
         warm = max(graphs.WARM_STEPS, 5 if self.world > 1 else 0)       # (N > 1: past the pick broadcasts of steps 1 and 3)
@@ -158,7 +172,27 @@ class StepRunner:
             self.engine.saved = None
             return None
         self._graphs = G
+        if graphs.MODE == "auto":
+            self._graph_trial = dict(replay=[], eager=[], now="replay")
         return G
+
+    def _graph_decide(self, key):
+        """End of auto mode's trial: medians of the event-timed forward + backward sections; the slower mode goes."""
+        tr, self._graph_trial = self._graph_trial, None
+        med = {}
+        for mode in ("replay", "eager"):
+            ts = []
+            for e0, e1 in tr[mode]:
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            med[mode] = ts[len(ts) // 2]
+        self.graph_trial_ms = med
+        if med["eager"] <= med["replay"]:
+            self._graph_choice[key] = "eager"
+            self._graphs = None                        # (its static activations go back to the allocator)
+        else:
+            self._graph_choice[key] = "replay"
 
     def current_lr(self):
         return float(self.lr(self.t)) if callable(self.lr) else float(self.lr)
@@ -186,6 +220,10 @@ class StepRunner:
         training = m.training and m.encoder_model.training
         fwd_kw = dict(training=training, weighted_sum=m.weighted_sum, lm_training=m._lm_training(), want_logits=False)
         G = self._step_graphs(wave, decoder_input_ids, labels, text, fwd_kw)
+        trial = self._graph_trial
+        if trial is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if G is not None:
             # the whole forward + backward as a chain of captured HIP graphs (graphs.py): same kernels, same arguments
             out = G.replay(wave, decoder_input_ids, labels, text)
@@ -198,6 +236,9 @@ class StepRunner:
                 eng.backward(gscale=1.0 / ga, zero_grads=first)
             finally:
                 eng.stage_cb = cb
+        if trial is not None:
+            ev[1].record()
+            trial[trial["now"]].append(ev)
         # LayerDrop: a layer is without a gradient for this update only if every micro-batch dropped it
         self._dropped_all = set(eng.last_dropped) if first else (self._dropped_all & set(eng.last_dropped))
         if not last:

@@ -154,9 +154,11 @@ LM = dict(model_type="bart", vocab_size=200, d_model=128, encoder_layers=2, deco
           decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256, max_position_embeddings=128)
 
 
-def _run_steps(use_graphs, steps, train=True, optimizer="sgd", lr=0.0, enc=ENC, lm=LM, batches=None):
+def _run_steps(use_graphs, steps, train=True, optimizer="sgd", lr=0.0, enc=ENC, lm=LM, batches=None, mode="1"):
+    from speechmix_amd import graphs
     from speechmix_amd.model import SpeechMixEED
     from speechmix_amd.trainer import StepRunner
+    graphs.MODE, graphs.ENABLED = mode, True          # "1": replay from the capture on (the default, "auto", times both and keeps the faster)
     g = torch.Generator().manual_seed(0)
     wave = (torch.randn(4, 12000, generator=g) * 0.1).cuda()
     labels = torch.randint(4, 200, (4, 6), generator=g).cuda()
@@ -239,6 +241,19 @@ def test_graph_replay_follows_new_inputs_and_falls_back_on_a_new_shape():
     graph, _, _ = _run_steps(True, len(mixed), batches=mixed)
     assert [s["graphed"] for s in graph] == [False] * 3 + [True] * 3 + [False] * 3 + [True] * 2
     _compare(eager, graph, offs)
+
+
+def test_auto_mode_times_both_and_keeps_one():
+    """SMX_STEP_GRAPHS=auto (the default): 3 eager steps, the capture, 3 replayed + 3 eager timed steps, then ONE mode for good;
+    whatever it picks, every step equals the eager run."""
+    eager, offs, _ = _run_steps(False, 14)
+    auto, _, r = _run_steps(True, 14, mode="auto")
+    assert [s["graphed"] for s in auto][:9] == [False] * 3 + [True] * 6          # (captured chain alive through the trial)
+    assert r.graph_trial_ms is not None and set(r.graph_trial_ms) == {"replay", "eager"}
+    choice = list(r._graph_choice.values())
+    assert choice in (["eager"], ["replay"])
+    assert all(s["graphed"] == (choice == ["replay"]) for s in auto[10:])
+    _compare(eager, auto, offs)
 
 
 @pytest.mark.parametrize("Cg,T,train", [(48, 499, True), (64, 250, True), (48, 203, False)])
