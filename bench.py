@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout / LayerDrop / SpecAugment off")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the extra p=0 pass reported beside the train-mode number")
+    ap.add_argument("--no-trainer-leg", action="store_true", help="skip the Trainer-style loop (model(...).backward() + optimizer) legs")
     ap.add_argument("--seed", type=int, default=None, help="seed the host streams (np.random: SpecAugment, torch: LayerDrop) for A/B runs")
     args = ap.parse_args()
 
@@ -351,6 +352,51 @@ def main():
         eval_ms = 1e3 * e2 / args.steps
         model.train()
 
+    # The drop-in path itself: what ref:train.py:291-330 runs through HF Trainer per step - `model(**batch)["loss"]`,
+    # `.backward()` (ONE autograd node over the engine), `clip_grad_norm_` over the parameters' `.grad` views of the flat buffer, the
+    # optimizer, `zero_grad` - on the same batch: once with HF's own Adafactor (Trainer's optim="adafactor": a Python loop over ~460
+    # tensors) and once with speechmix_amd.optim.FusedAdafactor (what `Trainer(optimizers=...)` can take instead).  Reported beside
+    # the headline, never instead of it; the headline is StepRunner.
+    trainer_path = None
+    if world == 1 and not args.no_trainer_leg:
+        trainer_path = {}
+        k = max(5, min(args.steps, 10))
+
+        def loop(opt, clip):
+            def one():
+                loss = model(wave, labels=labels)["loss"]
+                loss.backward()
+                if clip:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(k):
+                one()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - tq) / k
+        try:
+            from speechmix_amd.optim import FusedAdafactor
+            model.train(not args.eval_mode)
+            fused_ms = loop(FusedAdafactor(model, lr=5e-4, max_grad_norm=1.0), clip=False)
+            trainer_path["fused_adafactor"] = {"ms_per_step": round(fused_ms, 3), "value": round(B * CLIP_SECONDS / (fused_ms * 1e-3), 1),
+                                               "what": "model(...)['loss'].backward() + speechmix_amd.optim.FusedAdafactor(max_grad_norm=1.0).step() + zero_grad"}
+            try:
+                from transformers.optimization import Adafactor as HFAdafactor
+                model.store.external_updates = True          # (a foreign optimizer writes the fp32 masters: bf16 copies re-cast per forward)
+                hf_ms = loop(HFAdafactor([p for p in model.parameters() if p.requires_grad], lr=5e-4, scale_parameter=False,
+                                         relative_step=False, warmup_init=False), clip=True)
+                trainer_path["hf_adafactor"] = {"ms_per_step": round(hf_ms, 3), "value": round(B * CLIP_SECONDS / (hf_ms * 1e-3), 1),
+                                                "what": "the same loop with torch clip_grad_norm_ + transformers' Adafactor (Trainer's optim='adafactor')"}
+            except Exception as e:          # (transformers absent: the fused figure stands alone)
+                trainer_path["hf_adafactor"] = {"error": str(e)[:200]}
+            trainer_path["steps"] = k
+        except Exception as e:              # a reporting extra must never cost the bench line
+            trainer_path = {"error": str(e)[:300]}
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         ec, lc = model.encoder_model.config, model.decoder_model.config
@@ -376,6 +422,8 @@ def main():
                                  "(speechmix_amd/graphs.py)"}}
         if in_sync is not None:
             line["params_in_sync"] = in_sync
+        if trainer_path is not None:
+            line["trainer_path"] = trainer_path
         if world > 1:
             # why it scales the way it does: how long the gradient collectives ran beside backward and how much of that was
             # NOT hidden (compute stream waiting in GradReducer.finish), from the instrumented pass

@@ -36,14 +36,22 @@ def reduce_bucket(t: torch.Tensor, group=None, mode: Optional[str] = None):
         dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
         t.copy_(c)
         return
-    if mode == "rs_ag" and world > 1 and dist.get_backend(group) == "nccl":
+    if mode == "rs_ag" and world > 1:
         n = t.numel() - t.numel() % world
         if n:
             sh = n // world
             r = dist.get_rank(group)
             mine = t[r * sh:(r + 1) * sh]
-            dist.reduce_scatter_tensor(mine, t[:n], op=dist.ReduceOp.SUM, group=group)
-            dist.all_gather_into_tensor(t[:n], mine, group=group)
+            if dist.get_backend(group) == "nccl":
+                dist.reduce_scatter_tensor(mine, t[:n], op=dist.ReduceOp.SUM, group=group)
+                dist.all_gather_into_tensor(t[:n], mine, group=group)
+            else:
+                # gloo has no reduce-scatter: the same shard arithmetic on collectives it has (the CPU / shared-GPU tests run THIS
+                # branch, so the offsets above are exercised somewhere; RCCL's two calls have run on no hardware of this builder)
+                full = t[:n].clone()
+                dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+                shard = full[r * sh:(r + 1) * sh].clone()                       # what reduce_scatter_tensor would leave in `mine`
+                dist.all_gather([t[i * sh:(i + 1) * sh] for i in range(world)], shard, group=group)
         if n < t.numel():
             dist.all_reduce(t[n:], op=dist.ReduceOp.SUM, group=group)
         return

@@ -153,10 +153,18 @@ def _worker_modes(rank, world, port, q):
         ref = g.clone()
         dist.all_reduce(ref)
         out = {}
-        for mode in ("sum", "rs_ag", "bf16"):          # rs_ag falls back to the all-reduce on gloo (no reduce-scatter there)
+        for mode in ("sum", "rs_ag", "bf16"):          # rs_ag on gloo: the shard arithmetic on all_reduce + all_gather (dist.py)
             t = g.clone()
             reduce_bucket(t, mode=mode)
             out[mode] = (t - ref).abs().max().item()
+        # rs_ag with a bucket shorter than the world size, exactly divisible, and with a remainder of 1
+        for n in (1, 2, 1002):
+            torch.manual_seed(100 + rank)
+            t = torch.randn(n)
+            want = t.clone()
+            dist.all_reduce(want)
+            reduce_bucket(t, mode="rs_ag")
+            out[f"rs_ag_{n}"] = (t - want).abs().max().item()
         # tuner picks: rank 1 adopts rank 0's choice for a shared key and keeps its own extra key
         ops._TUNED.clear()
         ops._tuned_set(("shape", 1), 8 if rank == 0 else 12)
@@ -182,5 +190,6 @@ def test_allreduce_modes_and_shared_tuner_picks_gloo_world2():
         assert p.exitcode == 0
     for rank, out, picks in res:
         assert out["sum"] == 0.0 and out["rs_ag"] == 0.0
+        assert out["rs_ag_1"] == 0.0 and out["rs_ag_2"] == 0.0 and out["rs_ag_1002"] == 0.0
         assert 0.0 < out["bf16"] < 5e-2                       # bf16 rounding of the summed gradient, nothing worse
     assert res[0][2] == (8, None) and res[1][2] == (8, 13)

@@ -1,0 +1,101 @@
+"""Round-5 GPU tests, part b (run on the MI355X: `pytest -m gpu`).
+
+* `speechmix_amd.optim.FusedAdafactor` (the `torch.optim.Optimizer` front of the fused multi-tensor Adafactor step) against
+  `transformers.optimization.Adafactor` with HF Trainer's settings, stepped on the same model gradients;
+* `DistributedDataParallel(model, find_unused_parameters=True)` around the HIP model - the reference's real multi-GPU wrapper -
+  two ranks over gloo on the shared GPU, LayerDrop with different patterns per rank, requires_grad flips (item 7).
+"""
+import contextlib
+import io
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ENC = dict(model_type="wav2vec2", hidden_size=64, num_hidden_layers=3, num_attention_heads=2, intermediate_size=128,
+           conv_dim=[32] * 7, conv_kernel=[10, 3, 3, 3, 3, 2, 2], conv_stride=[5, 2, 2, 2, 2, 2, 2], num_conv_pos_embeddings=16,
+           num_conv_pos_embedding_groups=4, layerdrop=0.0, mask_time_prob=0.0, hidden_dropout=0.0, attention_dropout=0.0,
+           activation_dropout=0.0, feat_proj_dropout=0.0)
+LM = dict(model_type="bart", vocab_size=120, d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=2,
+          decoder_attention_heads=2, encoder_ffn_dim=128, decoder_ffn_dim=128, max_position_embeddings=128, dropout=0.0,
+          attention_dropout=0.0, activation_dropout=0.0)
+
+
+def _build():
+    from speechmix_amd.model import SpeechMixEED
+    with contextlib.redirect_stdout(io.StringIO()):
+        return SpeechMixEED(ENC, LM, down_scale=2, compute_dtype="fp32", init_seed=2).train()
+
+
+def test_fused_adafactor_optimizer_reproduces_transformers_adafactor():
+    """Five steps of `loss.backward(); clip; optimizer.step(); zero_grad` - HF's Adafactor (scale_parameter=False,
+    relative_step=False: what Trainer's optim="adafactor" builds) after torch's clip_grad_norm_ on one model, FusedAdafactor with
+    max_grad_norm folded in on its twin - leave the same parameters (fp32: 2e-5 of each tensor's range), with a frozen tensor
+    untouched and the learning rate read from param_groups every step (a scheduler's hook)."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.optimization import Adafactor
+    from speechmix_amd.optim import FusedAdafactor
+    a, b = _build(), _build()
+    for m in (a, b):
+        dict(m.named_parameters())["enc_to_dec_proj.bias"].requires_grad = False
+    hf = Adafactor([p for p in a.parameters() if p.requires_grad], lr=1e-2, scale_parameter=False, relative_step=False, warmup_init=False)
+    a.store.external_updates = True
+    fu = FusedAdafactor(b, lr=1e-2, max_grad_norm=0.5)
+    sched = torch.optim.lr_scheduler.LambdaLR(fu, lambda s: 1.0 / (1 + s))
+    g = torch.Generator().manual_seed(0)
+    p0 = b.store.master.clone()
+    for step in range(5):
+        wave = (torch.randn(3, 9000, generator=g) * 0.1).cuda()
+        labels = torch.randint(4, 120, (3, 6), generator=g).cuda()
+        for grp in hf.param_groups:
+            grp["lr"] = 1e-2 / (1 + step)
+        la = a(wave, labels=labels)["loss"]
+        la.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in a.parameters() if p.requires_grad], 0.5)
+        hf.step()
+        a.zero_grad(set_to_none=True)
+        lb = b(wave, labels=labels)["loss"]
+        lb.backward()
+        fu.step()
+        sched.step()
+        b.zero_grad(set_to_none=True)
+        assert abs(la.item() - lb.item()) <= 2e-4 * max(1.0, abs(la.item())), (step, la.item(), lb.item())
+    torch.cuda.synchronize()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    moved = 0
+    for n in pa:
+        x, y = pa[n].detach(), pb[n].detach()
+        scale = max(x.abs().max().item(), 1e-3)
+        assert (x - y).abs().max().item() <= 2e-5 * scale + 1e-7, (n, (x - y).abs().max().item(), scale)
+        o, k, _ = b.store.offsets[n]
+        moved += int(not torch.equal(p0[o:o + k].view_as(y), y))
+    o, k, _ = b.store.offsets["enc_to_dec_proj.bias"]
+    assert torch.equal(p0[o:o + k], b.store.master[o:o + k])                      # frozen: untouched
+    assert moved >= len(pa) - 3
+    # the optimizer state travels through state_dict (Trainer writes optimizer.pt at every checkpoint)
+    sd = fu.state_dict()
+    fu2 = FusedAdafactor(_build(), lr=1e-2)
+    fu2.load_state_dict(sd)
+    assert torch.equal(fu2.plan.row, fu.plan.row) and torch.equal(fu2.plan.col, fu.plan.col) and (fu2.plan.steps == fu.plan.steps).all()
+
+
+def test_ddp_wrapped_model_two_ranks_layerdrop_and_freezing():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "gpu_ddp_check.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(d)
+    assert d["tensors_checked"] > 150 and d["layers_dropped_on_rank0"] >= 3 and d["frozen_grads_none"]
+    assert d["worst_rel_err"] <= 1e-5, d
