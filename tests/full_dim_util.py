@@ -163,6 +163,27 @@ def oracle_run(c, ours, wave, labels, text, dt=torch.float32, threads=8):
     return got, grads
 
 
+def oracle_loss(c, ours, wave, labels, text, dt=torch.float32, threads=8):
+    """Forward-only loss of the CPU oracle in dtype `dt` (the loss-spread yardstick of tests/golden/make_bf16_yardstick_r5.py)."""
+    from oracle import speechmix_oracle as O
+    torch.set_num_threads(max(1, min(threads, len(os.sched_getaffinity(0)))))
+    ec, lc = ours.encoder_model.config.to_dict(), ours.decoder_model.config.to_dict()
+    leaves = {k: (v.detach().to(dt) if v.is_floating_point() else v) for k, v in ours.state_dict().items()
+              if not k.endswith(("embed_tokens.weight", "lm_head.weight", "nlp_emb.weight"))}
+    nl = ours.num_speech_encoder_layers
+    with torch.no_grad():
+        if c["kind"] == "eed":
+            out = O.speechmix_eed_forward(leaves, ec, lc, wave.to(dt), labels=labels, down_scale=c["ds"], num_speech_layers=nl)
+        else:
+            enc_sd, _, rest = O.split_state_dict(leaves)
+            last, _ = O.speech_encoder(enc_sd, ec, wave.to(dt), num_layers=nl)
+            x = O.length_adapters(rest, last, {2: 1, 4: 2, 8: 3}[c["ds"]])
+            emb = x @ rest["enc_to_dec_proj.weight"].t() + rest["enc_to_dec_proj.bias"]
+            dec_in = O.shift_tokens_right(labels, lc["pad_token_id"], lc["decoder_start_token_id"])
+            out = O.speechmix_self_losses(leaves, lc, emb, text, dec_in, labels)
+    return float(out["loss"])
+
+
 def hip_run(c, model, wave, labels, text):
     """The HIP path on the case (needs the GPU) -> (`got`, {name: grad})."""
     kw = {"text_input_ids": text} if text is not None else {}
