@@ -249,6 +249,7 @@ class Engine:
         if getattr(self, "_side_active", False):          # join the LM stage's weight-gradient stream
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_active = False
+            self._head_ev = None
             ops.GEMM_CONCURRENT = False
         if self.folds is not None:
             self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
@@ -2071,6 +2072,14 @@ class Engine:
                  batch_a=Lt * d, batch_b=Lt * S, batch_c=S * d)
         return loss, dhs
 
+    def _wait_head_wgrad(self):
+        """The tied embedding's gradient is about to receive scatter-added token-embedding gradients on this stream: the head's
+        weight gradient (second stream, lm_bwd) must have written it first."""
+        ev = getattr(self, "_head_ev", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._head_ev = None
+
     def lm_bwd(self, dlogits, sv, gscale, extra_denc=None):
         """dlogits [B*Ld, Vp] compute dtype.  Returns grad wrt inputs_embeds [B*S, d] (or None for token input)."""
         lc, lp = self.lc, self.lp
@@ -2099,9 +2108,17 @@ class Engine:
                     self.wgrad(dws, y[r0:r0 + n], self.G(head), n, V, d, dyv=view(Vp), alpha=a, side_ok=False)
                 self.dgrad(dws, self.W(head), dy[r0:r0 + n], n, V, d, av=view(Vp), alpha=a)
         else:
-            if lm_trainable:
-                self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a, side_ok=False)   # (tied embedding)
+            # the data gradient first: the decoder's backward chain hangs on it.  The head's weight gradient (dE = dlogits^T y:
+            # 79 GF, ~0.4 ms) goes to the second stream like every other weight gradient of the stage (round 5; rounds 1-4 kept it
+            # on the main stream, in front of the chain, because the tied embedding also receives the scatter-added gradients of
+            # the token embeddings: those launches now wait for `_head_ev`, which has long passed when they come up)
             self.dgrad(dlogits, self.W(head), dy, Md, V, d, av=view(Vp), alpha=a)
+            if lm_trainable:
+                on_side = getattr(self, "_side_active", False) and os.environ.get("SMX_HEAD_WGRAD_SIDE", "1") != "0"
+                self.wgrad(dlogits, sv["dec_out"], self.G(head), Md, V, d, dyv=view(Vp), alpha=a, side_ok=on_side)   # (tied embedding)
+                if on_side:
+                    self._head_ev = torch.cuda.Event()
+                    self._head_ev.record(self._side)
         if t5:
             dy = self.ln_bwd(dy, sv["dec_final_ln"], lp + "decoder.final_layer_norm.weight", None, Md, d, rms=True)
         elif lc.model_type == "mbart":
@@ -2154,6 +2171,7 @@ class Engine:
         if t5:
             dy = self._dropped(dy, sv["d_dec_in"], Md * d)
         if self.tr(emb_name):
+            self._wait_head_wgrad()
             ops.embed_bwd(sv["dec_ids"], dy, self.G(emb_name), Md, d, escale, self.dt)
         # ---- text encoder
         dh = denc[0]
@@ -2183,6 +2201,7 @@ class Engine:
             dh = self._dropped(dh, sv["d_enc_in"], Ms * d)
         if sv["enc_ids"] is not None:
             if self.tr(emb_name):
+                self._wait_head_wgrad()
                 ops.embed_bwd(sv["enc_ids"], dh, self.G(emb_name), Ms, d, escale, self.dt)
             return None
         return dh
@@ -2295,6 +2314,7 @@ class Engine:
             if self.tr(emb_name):
                 escale = math.sqrt(dd) if (lc.scale_embedding and not t5) else 1.0
                 dp = de3[:, :P].contiguous().view(B * P, dd)
+                self._wait_head_wgrad()
                 ops.embed_bwd(sv["prompt_ids"].repeat(B).contiguous(), dp, self.G(emb_name), B * P, dd, escale, self.dt)
             de = de3[:, P:].contiguous().view(B * (S2 - P), dd)
         self._stage("lm")

@@ -199,6 +199,11 @@ class StepGraphs:
         cb = eng.stage_cb
         sr = getattr(eng, "stage_ranges", None) or {}
         c = self.carry
+        tr = getattr(self, "trace", None)            # tools/gpu_stage_compare.py: (name, HIP event) after every graph of the chain
+        if tr is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            tr.append(("start", ev))
         for name, g in self.graphs:
             if name.startswith("enc_fwd"):
                 i = int(name[7:])
@@ -216,6 +221,10 @@ class StepGraphs:
                         cb(name[6:])
                     continue
             g.replay()
+            if tr is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                tr.append((name, ev))
             if cb is not None and name.startswith("stage:"):
                 cb(name[6:])
         eng.last_dropped = [i for i in range(self.L) if not kept[i]]
