@@ -278,6 +278,11 @@ def main():
                 and runner._graph_failures < 2 and setup_steps < 16:
             loss = runner.step(wave, labels)
             setup_steps += 1
+    # (what the set-up decided for THIS configuration: the eval leg below is another configuration with its own capture and trial)
+    graph_info = {"step_graphs": runner._graphs is not None, "step_graphs_mode": _graphs.MODE,
+                  "graphs_per_step": len(runner._graphs.graphs) if runner._graphs is not None else 0,
+                  "trial_fwd_bwd_ms": {k: round(v, 3) for k, v in runner.graph_trial_ms.items()} if runner.graph_trial_ms else None,
+                  "setup_steps_before_warmup": setup_steps}
     for _ in range(args.warmup):
         loss = runner.step(wave, labels)
     if world > 1:
@@ -412,14 +417,11 @@ def main():
                                        "32 label tokens, fwd+bwd+allreduce+clip+" + {"adafactor": "Adafactor", "adamw": "AdamW"}[args.optimizer] + ", " + mode,
                            "global_batch": world * B, "clip_seconds": CLIP_SECONDS, "parallelism": f"dp{world}"},
                 "final_loss": round(final_loss, 4),
-                "host": {"enqueue_ms_per_step": round(1e3 * host_elapsed / args.steps, 3),
-                         "step_graphs": runner._graphs is not None, "step_graphs_mode": _graphs.MODE,
-                         "trial_fwd_bwd_ms": runner.graph_trial_ms,
-                         "graphs_per_step": len(runner._graphs.graphs) if runner._graphs is not None else 0,
-                         "setup_steps_before_warmup": setup_steps,
+                "host": {"enqueue_ms_per_step": round(1e3 * host_elapsed / args.steps, 3), **graph_info,
                          "note": "wall time of one StepRunner.step call on the host with an empty queue ahead of it (median of 5, outside "
                                  "the timed region); forward + backward replayed from captured HIP graphs when step_graphs is true "
-                                 "(speechmix_amd/graphs.py)"}}
+                                 "(speechmix_amd/graphs.py; mode auto: the set-up times 3 replayed and 3 eager steps - "
+                                 "trial_fwd_bwd_ms - and keeps the faster)"}}
         if in_sync is not None:
             line["params_in_sync"] = in_sync
         if trainer_path is not None:

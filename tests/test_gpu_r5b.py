@@ -106,3 +106,22 @@ def test_ddp_wrapped_model_two_ranks_layerdrop_and_freezing():
     print(d)
     assert d["tensors_checked"] > 150 and d["layers_dropped_on_rank0"] >= 3 and d["frozen_grads_none"]
     assert d["worst_rel_err"] <= 1e-5, d
+
+
+def test_two_ranks_on_one_gpu_with_the_replayed_step():
+    """The N > 1 step with forward + backward replayed from captured graphs (SMX_STEP_GRAPHS=1): the replay reports every finished
+    stage to dist.GradReducer BETWEEN two graphs, exactly where the eager backward does, so the bucketed reduction still overlaps
+    the rest of backward.  Two ranks on cuda:0 over gloo through bench.py's own launch path, per-rank LayerDrop / SpecAugment
+    draws, 6 set-up + 2 warm-up + 4 timed steps (the capture happens after five eager steps when world > 1): one JSON line,
+    `host.step_graphs` true, parameters bit-identical on both ranks after the steps, a finite loss."""
+    env = dict(os.environ, SMX_BENCH_SHARED_GPU="1", SMX_BENCH_CHECK_SYNC="1", SMX_STEP_GRAPHS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "4",
+                        "--no-cpu-baseline", "--no-eval-leg", "--no-profile", "--seed", "3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["host"]["step_graphs"] is True and d["host"]["graphs_per_step"] >= 20, d["host"]
+    assert d.get("params_in_sync") is True, d
+    assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 50

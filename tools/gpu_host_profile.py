@@ -8,12 +8,16 @@ from speechmix_amd.trainer import StepRunner
 from bench import synth_batch
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+from speechmix_amd import graphs as _g
+# the EAGER host is what this tool profiles by default; SMX_STEP_GRAPHS=1: the step replayed from captured graphs
+_g.MODE = os.environ.get("SMX_STEP_GRAPHS", "0")
+_g.ENABLED = _g.MODE != "0"
 with contextlib.redirect_stdout(io.StringIO()):
     model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", share_layer_ratio=0, down_scale=2, compute_dtype="bf16")
 model.train()
 runner = StepRunner(model, lr=5e-4, optimizer="adafactor")
 wave, labels = synth_batch(32, model.decoder_model.config.vocab_size, 0, torch.device("cuda:0"))
-for _ in range(4):
+for _ in range(8):
     runner.step(wave, labels)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
