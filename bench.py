@@ -271,11 +271,14 @@ def main():
     # Set-up (untimed, ahead of the W warm-up steps): the step's forward + backward are replayed from captured HIP graphs
     # (speechmix_amd/graphs.py; SMX_STEP_GRAPHS=0: eager) once the configuration has run a few eager steps - kernel picks, the
     # first-write gradient ranges - so the capture must not land inside the timed region whatever W is.
-    setup_steps = 0
+    setup_steps = n_setup = 0
     from speechmix_amd import graphs as _graphs
     if _graphs.ENABLED:
-        while (runner._graphs is None or runner._graph_trial is not None) and not runner._graph_choice \
-                and runner._graph_failures < 2 and setup_steps < 16:
+        # a FIXED number of steps on every rank (each step holds collectives when N > 1): the eager steps before the capture, the
+        # capturing step, and in `auto` mode the timed trial of both schedules + the step that decides
+        warm = max(_graphs.WARM_STEPS, 5 if world > 1 else 0)
+        n_setup = warm + 1 + (2 * _graphs.TRIAL_STEPS + 1 if _graphs.MODE == "auto" else 0)
+        for _ in range(n_setup):
             loss = runner.step(wave, labels)
             setup_steps += 1
     # (what the set-up decided for THIS configuration: the eval leg below is another configuration with its own capture and trial)
@@ -338,7 +341,7 @@ def main():
     eval_ms = None
     if not args.eval_mode and not args.no_eval_leg:
         model.eval()
-        for _ in range(12 if _graphs.ENABLED else 2):         # (another configuration: its own eager steps, capture and trial)
+        for _ in range(n_setup + 1 if _graphs.ENABLED else 2):          # (another configuration: its own eager steps, capture and trial)
             runner.step(wave, labels)
         if world > 1:
             dist.barrier()

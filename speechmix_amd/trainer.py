@@ -187,10 +187,8 @@ class StepRunner:
                 ts.append(e0.elapsed_time(e1))
             ts.sort()
             med[mode] = ts[len(ts) // 2]
-        if self.world > 1:                          # every rank keeps the same mode: the decision is made on the ranks' mean timings
-            t = torch.tensor([med["replay"], med["eager"]], dtype=torch.float64, device=self.store.device)
-            dist.all_reduce(t)
-            med = dict(replay=float(t[0]) / self.world, eager=float(t[1]) / self.world)
+        # (every rank decides for itself, without a collective: a rank whose capture failed never gets here, and the two schedules
+        # issue the same kernels and the same reductions in the same order - ranks in different modes stay bit-identical)
         self.graph_trial_ms = med
         if med["eager"] <= med["replay"]:
             self._graph_choice[key] = "eager"
