@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of one environment switch:  bash tools/r5_ab_env.sh VAR OFF_VALUE ON_VALUE [pairs] [extra pytest -k expr]
+# same-box A/B of one environment switch:  bash tools/ab_env.sh VAR OFF_VALUE ON_VALUE [pairs] [extra pytest -k expr]
 cd "$(dirname "$0")/.."
 VAR=$1; OFF=$2; ON=$3; PAIRS=${4:-3}
 O=gpurun_out/r5env_$VAR

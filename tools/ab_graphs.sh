@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: captured-step tests, then eager vs graph-replayed bench (same box, seeded), host time per step, kernel-trace timelines
+# captured-step tests, then eager vs graph-replayed bench (same box, seeded), host time per step, kernel-trace timelines
 cd "$(dirname "$0")/.."
 O=gpurun_out/r5ab
 mkdir -p $O
