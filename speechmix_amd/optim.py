@@ -52,7 +52,11 @@ class FusedAdafactor(torch.optim.Optimizer):
         st, g = self.store, self.param_groups[0]
         # HF skips parameters without a gradient: frozen ones (requires_grad flipped by the FreezingCallback), tensors whose .grad
         # is None, and - on one GPU - the layers LayerDrop skipped in this step's forward (their flat slices hold zeros)
-        dropped = set(getattr(self.model.engine, "last_dropped", ()) or ())
+        # (under DistributedDataParallel the all-reduce gives every tensor a gradient - other ranks kept the layer - so nothing is
+        # skipped for LayerDrop there, exactly as StepRunner does)
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        dropped = set() if multi else set(getattr(self.model.engine, "last_dropped", ()) or ())
         active = [bool(p.requires_grad and p.grad is not None and l not in dropped)
                   for p, l in zip((st.params[nm] for nm in self.names), self._layer)]
         sh = None if st.shadow is st.master else st.shadow
