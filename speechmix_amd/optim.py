@@ -40,6 +40,8 @@ class FusedAdafactor(torch.optim.Optimizer):
         self.plan = ops.AdafactorPlan([(st.offsets[nm][0], st.offsets[nm][2]) for nm in self.names], st.device)
         pre = model.engine.ep + "encoder.layers."
         self._layer = [(int(nm[len(pre):].split(".", 1)[0]) if nm.startswith(pre) else -1) for nm in self.names]
+        self._params = params
+        self._gptr = [st.g(nm).data_ptr() for nm in self.names]
         st.external_updates = False            # this optimizer refreshes the bf16 compute copies itself
         st.refresh_shadow(force=True)
 
@@ -57,8 +59,15 @@ class FusedAdafactor(torch.optim.Optimizer):
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         dropped = set() if multi else set(getattr(self.model.engine, "last_dropped", ()) or ())
-        active = [bool(p.requires_grad and p.grad is not None and l not in dropped)
-                  for p, l in zip((st.params[nm] for nm in self.names), self._layer)]
+        active = []
+        for nm, l, p, gp in zip(self.names, self._layer, self._params, self._gptr):
+            on = bool(p.requires_grad and p.grad is not None and l not in dropped)
+            active.append(on)
+            # `.grad` normally IS the parameter's slice of the flat gradient (FlatStore.publish_grads).  A wrapper that installs its
+            # own gradient tensors (DistributedDataParallel's bucket views) leaves the reduced values there: bring them over
+            if on and p.grad.data_ptr() != gp:
+                dst = st.g(nm)
+                dst.copy_(p.grad.reshape(dst.shape))
         sh = None if st.shadow is st.master else st.shadow
         self.plan.step(st.master, st.grad, sh, float(g["lr"]), active=active, decay_rate=g["decay_rate"], eps1=g["eps1"],
                        clip_threshold=g["clip_threshold"], grad_scale=1.0, max_grad_norm=float(g["max_grad_norm"] or 0.0))
