@@ -38,7 +38,10 @@ if __name__ == "__main__":
     labels = torch.randint(4, V, (B, 32), generator=g).cuda()
     text = torch.randint(4, V, (B, 33), generator=g).cuda() if cfg == "5" else None
     runner = StepRunner(model, lr=1e-5, optimizer=os.environ.get("SMX_OPT", "adafactor"))
-    for i in range(3):
+    from speechmix_amd import graphs, ops
+    # set-up as in bench.py: eager steps, the capture, and in `auto` mode the timed trial of both schedules
+    n_setup = graphs.WARM_STEPS + 1 + (2 * graphs.TRIAL_STEPS + 1 if graphs.MODE == "auto" else 0) if graphs.ENABLED else 3
+    for i in range(n_setup):
         loss = runner.step(wave, labels, text_input_ids=text)
     torch.cuda.synchronize()
     mem = torch.cuda.max_memory_allocated() / 1e9
@@ -47,6 +50,26 @@ if __name__ == "__main__":
         loss = runner.step(wave, labels, text_input_ids=text)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # roofline object by bench.py's fixed rule (the GEMM kernel family with the largest share of the GEMM flops), from the same
+    # steps repeated with HIP events around every GEMM launch (eager: events cannot be recorded inside a replayed graph)
+    prof = ops.GemmProfile()
+    ops.GEMM_PROFILE = prof
+    for i in range(steps):
+        runner.step(wave, labels, text_input_ids=text)
+    torch.cuda.synchronize()
+    ops.GEMM_PROFILE = None
+    fams = prof.families()
+    dom = max(fams, key=lambda k: fams[k]["flops"])
+    fd, allg, enc = fams[dom], prof.robust(), prof.by_tag("enc_layer")
+    PEAK = 2500.0
+    roofline = {"kernel": dom + " (all instantiations)", "bound": "mfma", "achieved": round(fd["tflops"], 1), "peak": PEAK, "unit": "TFLOP/s",
+                "frac": round(fd["tflops"] / PEAK, 4), "traffic": None, "launches_per_step": round(fd["launches"] / steps, 1),
+                "avg_launch_us": round(1e3 * fd["total_ms"] / fd["launches"], 2), "flops_per_launch": round(fd["flops"] / fd["launches"]),
+                "flops_share_of_gemms": round(fd["flops"] / max(allg["flops"], 1.0), 3),
+                "encoder_gemms_frac": round(enc["tflops"] / PEAK, 4) if enc["launches"] else None,
+                "all_gemms_frac": round(allg["tflops"] / PEAK, 4),
+                "step_frac": round(allg["flops"] / steps / dt / 1e12 / PEAK, 4),
+                "rule": "kernel family with the largest share of GEMM flops; launches x median per (variant, shape); step_frac: GEMM flops only"}
     if os.environ.get("SMX_TUNE_DUMP"):
         us = lambda t: f"{t*1e3:8.1f}" if t is not None else "       -"
         for rec in _ops.TUNE_LOG:
@@ -55,5 +78,6 @@ if __name__ == "__main__":
     print(json.dumps({"config": int(cfg), "workload": NAMES[cfg], "mode": mode, "batch": B, "clip_seconds": 10.0, "steps": steps,
                       "ms_per_step": round(dt * 1e3, 2), "audio_s_per_s": round(B * 10 / dt, 1), "dtype": "bf16",
                       "optimizer": "adafactor", "params_M": round(model.store.total / 1e6, 1), "peak_mem_GB": round(mem, 1),
-                      "final_loss": round(loss.item(), 4), "n_gpus": 1,
+                      "final_loss": round(loss.item(), 4), "n_gpus": 1, "roofline": roofline,
+                      "step_graphs": runner._graphs is not None, "graph_trial_fwd_bwd_ms": runner.graph_trial_ms,
                       "ffn_ld_padding": os.environ.get("SMX_PAD_FFN", "1") != "0"}), flush=True)
