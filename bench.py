@@ -475,7 +475,7 @@ def main():
                                      for k, v in fams.items()}
             # HBM-side bytes per launch of that family from the committed PMC passes of the same command (tools/pmc_traffic.py);
             # counters cannot be collected inside this process - `traffic_source` names the file
-            pmc = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r04_pmc.json", "r03_pmc.json"))
+            pmc = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"))
                         if os.path.exists(f)), "")
             if pmc:
                 stems = {"gemm_bf16_pp_kernel": ("gemm_bf16_pp_kernel", "gemm_bf16_pp_group_kernel")}.get(dom, (dom,))
