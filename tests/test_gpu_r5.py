@@ -243,6 +243,57 @@ def test_graph_replay_follows_new_inputs_and_falls_back_on_a_new_shape():
     _compare(eager, graph, offs)
 
 
+def test_graph_replay_of_speechmixself_with_a_t5_teacher_pass_and_of_a_weighted_sum_model():
+    """The other model families through the captured chain: SpeechMixSelf (wav2vec2 -> frozen T5 in eval mode, text teacher pass,
+    CE + KLD + MSE; relative-position buckets cached on the device; only the speech side's dropout is on) in train mode - 9 steps
+    eager vs replayed, weight-matrix gradients bit-identical - and a weighted-sum SpeechMixEED in EVAL mode (train mode of such
+    models stays eager: a LayerDrop-dropped layer's share of the weighted gradient is added outside its graph)."""
+    from speechmix_amd import graphs
+    from speechmix_amd.model import SpeechMixEED, SpeechMixSelf
+    from speechmix_amd.trainer import StepRunner
+    from tests.golden_util import load_case
+    graphs.MODE, graphs.ENABLED = "1", True
+    sd, inp, gold, m = load_case("self_w2v2_t5")
+    res = {}
+    for use in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = SpeechMixSelf(m["enc_cfg"], m["lm_cfg"], share_layer_ratio=0.5, down_scale=4, compute_dtype="bf16")
+        model.load_state_dict(sd, strict=False)
+        model.train()
+        r = StepRunner(model, lr=0.0, optimizer="sgd", max_grad_norm=0.0, seed=9)
+        r.use_graphs = use
+        steps = []
+        for _ in range(9):
+            loss = r.step(inp["input_values"], inp["labels"], text_input_ids=inp["text_input_ids"])
+            torch.cuda.synchronize()
+            steps.append(dict(grad=model.store.grad.clone(), dropped=list(model.engine.last_dropped), loss=float(loss.item()),
+                              graphed=r._graphs is not None))
+        res[use] = (steps, {n: (o, k, sh) for n, (o, k, sh) in model.store.offsets.items()})
+    assert [s["graphed"] for s in res[True][0]] == [False] * 3 + [True] * 6
+    _compare(res[False][0], res[True][0], res[True][1])
+    assert res[True][0][-1]["grad"].abs().max().item() > 0
+    # weighted sum, eval mode
+    res = {}
+    g = torch.Generator().manual_seed(0)
+    wave = (torch.randn(4, 12000, generator=g) * 0.1).cuda()
+    labels = torch.randint(4, 200, (4, 6), generator=g).cuda()
+    for use in (False, True):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = SpeechMixEED(ENC, LM, down_scale=2, compute_dtype="bf16", init_seed=0, weighted_sum=True).eval()
+        r = StepRunner(model, lr=0.0, optimizer="sgd", max_grad_norm=0.0, seed=9)
+        r.use_graphs = use
+        steps = []
+        for _ in range(6):
+            loss = r.step(wave, labels)
+            torch.cuda.synchronize()
+            steps.append(dict(grad=model.store.grad.clone(), dropped=[], loss=float(loss.item()), graphed=r._graphs is not None))
+        res[use] = (steps, {n: (o, k, sh) for n, (o, k, sh) in model.store.offsets.items()})
+    assert res[True][0][-1]["graphed"]
+    _compare(res[False][0], res[True][0], res[True][1])
+    o, k, _ = res[True][1]["weights_sum"]
+    assert res[True][0][-1]["grad"][o:o + k].abs().max().item() > 0          # the layer weights did receive a gradient
+
+
 def test_auto_mode_times_both_and_keeps_one():
     """SMX_STEP_GRAPHS=auto (the default): 3 eager steps, the capture, 3 replayed + 3 eager timed steps, then ONE mode for good;
     whatever it picks, every step equals the eager run."""
