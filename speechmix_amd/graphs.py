@@ -26,9 +26,8 @@ from __future__ import annotations
 
 import os
 import warnings
-from typing import Dict, List, Optional
+from typing import Dict, List
 
-import numpy as np
 import torch
 
 from . import ops
@@ -61,7 +60,6 @@ class StepGraphs:
         self.out = None
         self.static = {}
         self._cur = None
-        self._names = []
 
     # ---- called by the engine during the capture pass
     def boundary(self, closed, carry):
