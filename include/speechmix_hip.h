@@ -201,7 +201,7 @@ int smx_dropout(const void* x, void* out, long long n, float p, unsigned seed, i
  * step captured into a HIP graph bakes its seed arguments; setting a fresh key ahead of every replay is what makes the
  * replayed step draw fresh masks (the reference draws from torch's Philox stream per call: TF sites above).  Rows of
  * smx_mask_rows / smx_mask_rows_bwd lists that are negative are skipped (fixed-capacity SpecAugment row lists of such steps). */
-int smx_set_step_key(unsigned key, hipStream_t stream);
+int smx_set_step_key(unsigned key, hipStream_t stream);   /* (the library's smx_step_key_addr_<unit> exports are its own plumbing: the key word of each translation unit) */
 /* dst[0 .. bytes) = src[0 .. bytes) as one kernel on `stream` (16-byte aligned; src may be pinned host memory): the copies of a
  * replayed step - inputs, SpecAugment rows, a LayerDrop-dropped layer's pass-through (TF:models/wav2vec2/modeling_wav2vec2.py:
  * 709-723 skips the layer; the captured graphs of the neighbours read fixed buffers) - without the runtime's copy path */
