@@ -50,7 +50,8 @@ __device__ __forceinline__ constexpr int fr_slot(int blk) { return (PAR && blk >
 //            spare-slot A blocks at its start, A blocks 0..5 each right after the last MFMA on its slot; ISSUE1: two units.
 // sched_barrier(0) after every A block pins the interleave.
 // SMX_FR_LAB (ablation builds, tools/lab/build_variant.sh; results are garbage, only the time means something): 1 = the K loop without
-// its fragment reads (registers keep the item's first fragments), 2 = without its MFMAs.
+// its fragment reads (registers keep the item's first fragments), 2 = without its MFMAs, 3 = every LDS-DMA fill re-reads the item's first
+// K tile (cache hits), 4 = no fills inside the K loop.
 #ifndef SMX_FR_LAB
 #define SMX_FR_LAB 0
 #endif
@@ -80,9 +81,10 @@ __device__ __forceinline__ void fr_pass(f32x4_t (&acc)[NB][4], FRFrags<NB>& f, c
             if (g < NB - 2) f.a[g] = fr_afrag<A_RC, NB>(nstage, g, 1 - PAR, wr, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (ISSUE != 0) {
-            if (g == 1) { if (ISSUE == 1) is.template issue<0>(tid); else is.template issue<2>(tid); __builtin_amdgcn_sched_barrier(0); }
-            if (g == NB - 3) { if (ISSUE == 1) is.template issue<1>(tid); else is.template issue<3>(tid); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (ISSUE != 0 && SMX_FR_LAB != 4) {
+            constexpr bool FZ = SMX_FR_LAB == 3;
+            if (g == 1) { if (ISSUE == 1) is.template issue<0, FZ>(tid); else is.template issue<2, FZ>(tid); __builtin_amdgcn_sched_barrier(0); }
+            if (g == NB - 3) { if (ISSUE == 1) is.template issue<1, FZ>(tid); else is.template issue<3, FZ>(tid); __builtin_amdgcn_sched_barrier(0); }
         }
     }
 }
@@ -96,7 +98,15 @@ __device__ __forceinline__ void fr_read_first(FRFrags<NB>& f, const char* stage,
     for (int g = 0; g < NB; ++g) f.a[g] = fr_afrag<A_RC, NB>(stage, g, 0, wr, lane);
 }
 
+// SMX_FR_TRACE (lab builds, tools/gpu_fr_timeline.py; PP_STAMP in gemm_pp.h): wave 0 of every workgroup stamps the 100-MHz clock at kernel
+// entry, after the prologue and, per work item, at its start, after its K loop and after its epilogue (stores issued)
+#define FR_STAMP(i) PP_STAMP(i)
+
+#if SMX_FR_LAB == 5          // (timing only: the K tile's barrier without the wait for the fills)
+#define FR_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define FR_SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 template <bool A_RC, bool B_RC, int EPI, bool BVIEW, bool GRP, int MT>
 __device__ __forceinline__ void fr_kernel_body() {
@@ -110,17 +120,19 @@ __device__ __forceinline__ void fr_kernel_body() {
     int W = ntm * ntn * p.nbatch * p.split_k;
     if constexpr (GRP) W = pp_group().W;
 
+    FR_STAMP(0);
     PPIssue<A_RC, B_RC, BVIEW, GRP, MT> is;
     is.dv.init(p, ntm, ntn, MT);
     is.g = 0;
     is.q = blockIdx.x; is.qstep = gridDim.x;
-    is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
+    is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0; is.ahead = 0;
     is.wave_u = __builtin_amdgcn_readfirstlane(wave);
     is.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     is.K = p.K;
     is.load_item(tid);
 
-    // prologue: K tile 0 of the stream entirely, the first two units of tile 1; tile 0 is resident after the barrier
+    // prologue: K tile 0 of the stream entirely and the first two units of tile 1 (EARLY: all of tile 1); tile 0 is resident after the barrier
+    constexpr bool EARLY = MT == 192 && SMX_FR_LAB != 4;          // see below the K loop
     {
         bool all = true;
         all &= is.template issue<0>(tid);
@@ -129,11 +141,21 @@ __device__ __forceinline__ void fr_kernel_body() {
         all &= is.template issue<3>(tid);
         all &= is.template issue<0>(tid);
         all &= is.template issue<1>(tid);
-        if (all) PP_WAITV(4);
-        else PP_WAITV(0);
+        if constexpr (EARLY) {
+            all &= is.template issue<2>(tid);
+            all &= is.template issue<3>(tid);
+            is.ahead = 2;
+            if (!all) PP_WAITV(0);
+            else if constexpr (!A_RC) PP_WAITV(7);          // (the 64-row A unit is one instruction)
+            else PP_WAITV(8);
+        } else {
+            if (all) PP_WAITV(4);
+            else PP_WAITV(0);
+        }
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    FR_STAMP(1);
 
     f32x4_t acc[NB][4];
     FRFrags<NB> f;
@@ -157,6 +179,7 @@ __device__ __forceinline__ void fr_kernel_body() {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[a][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         ++items;
+        FR_STAMP(3 * items - 1);
         if (fast_epi && wr == 0) {          // bias slice of this item -> LDS (retired by the item's first SYNC)
             const SmxGemmParams& pq = pp_kernarg_g<GRP>(gc);
             if (pq.bias) {
@@ -171,7 +194,8 @@ __device__ __forceinline__ void fr_kernel_body() {
         for (int t = 0; t < it.nk; ++t) {
             const char* cur = smem + (seq & 1) * PP_STAGE;
             const char* oth = smem + ((seq & 1) ^ 1) * PP_STAGE;
-            // H0 (k 0..31 of tile t): pass 0 issues the last two units of stream tile seq+1, pass 1 reads k 32..63 of tile t
+            // H0 (k 0..31 of tile t): pass 0 issues the last two units of stream tile seq+1 (in an item's first tile they are on their way
+            // already - is.ahead, see below the loop - and the two calls return at once), pass 1 reads k 32..63 of tile t
             fr_pass<A_RC, B_RC, 0, 0, true, 2, NB>(acc, f, cur, cur, is, tid, lane, wr, wc);
             fr_pass<A_RC, B_RC, 0, 1, true, 0, NB>(acc, f, cur, cur, is, tid, lane, wr, wc);
             // H1 (k 32..63): pass 0; SYNC: stream tile seq+1 resident for everyone, every read of tile t done -> its stage is free;
@@ -180,8 +204,22 @@ __device__ __forceinline__ void fr_kernel_body() {
             FR_SYNC();
             // (in the item's last tile these reads fetch the next item's first fragments and are dropped: one copy of the pass)
             fr_pass<A_RC, B_RC, 1, 1, true, 1, NB>(acc, f, cur, oth, is, tid, lane, wr, wc);
+#if SMX_FR_TRACE
+            if (items == (gridDim.x * 2 <= W ? 2 : 1) && t < 16) FR_STAMP(45 + t);          // (per K tile, one item of every workgroup)
+#endif
             ++seq;
         }
+        // EARLY (192-row tiles; the 256-row forms spill with it): the last two units of the NEXT item's second K tile go out here, ahead of the
+        // epilogue, instead of in that item's first half step: they
+        // are first touches of new operand rows (HBM latency) and the item's first barrier used to wait for them ~0.5 us (round 5 timeline).  Their
+        // stage is free: nothing reads this item's last stage after the barrier inside its last tile.
+        if constexpr (EARLY) {
+            is.template issue<2, SMX_FR_LAB == 3>(tid);
+            is.template issue<3, SMX_FR_LAB == 3>(tid);
+            is.ahead = 2;          // the next two calls for these kinds (the next item's first pass) are answered by these
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        FR_STAMP(3 * items);
         if (fast_epi) {
             pp_epilogue_fast<EPI, GRP, NB, B_RC>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.n0, smem + PP_BIAS_OFF + (items & 1) * 1024, it.zc,
                                        it.ze, lane, gc);
@@ -189,6 +227,7 @@ __device__ __forceinline__ void fr_kernel_body() {
             pp_epilogue<GRP, NB, B_RC>(acc, it.m0 + wr * (MT / 2), it.n0 + wc * 64, it.zc, it.zbias, it.ze, lane, gc);
         }
         __builtin_amdgcn_sched_barrier(0);
+        FR_STAMP(3 * items + 1);
     }
 }
 

@@ -16,6 +16,20 @@
 
 typedef __attribute__((ext_vector_type(4))) int pp_rsrc_t;
 
+// SMX_FR_TRACE (lab builds of gemm_fr.hip, tools/gpu_fr_timeline.py): thread 0 of every workgroup stamps the 100-MHz clock into slot i
+#ifndef SMX_FR_TRACE
+#define SMX_FR_TRACE 0
+#endif
+#if SMX_FR_TRACE
+__device__ unsigned long long smx_fr_trace_buf[256 * 64];
+extern "C" int smx_fr_trace_read(void* host, unsigned long long bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(smx_fr_trace_buf), bytes) == hipSuccess ? SMX_OK : -5;
+}
+#define PP_STAMP(i) do { if (threadIdx.x == 0 && (i) < 64 && blockIdx.x < 256) smx_fr_trace_buf[blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ pp_rsrc_t pp_make_rsrc(const void* base) {
     const unsigned long long b = (unsigned long long)base;
     pp_rsrc_t r;
@@ -167,7 +181,7 @@ struct PPOperand {
         const float rrpb = 1.0f / (float)max(v.rows_per_batch, 1);
         const int lane = tid & 63, wave = tid >> 6;
         if (!RC) {
-            soff = (unsigned)k0 * 2u;
+            soff = __builtin_amdgcn_readfirstlane((unsigned)k0 * 2u);          // (uniform: kept in a scalar register)
             sstep = BK * 2u;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -198,7 +212,7 @@ struct PPOperand {
                 rt[0] = k - rb[0] * (v.rows_per_batch > 0 ? v.rows_per_batch : 0);
                 view_rows(v);
             } else {
-                soff = (unsigned)((long long)k0 * v.ld * 2);
+                soff = __builtin_amdgcn_readfirstlane((unsigned)((long long)k0 * v.ld * 2));
                 sstep = (unsigned)(v.ld * BK * 2);
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) voff[0][ps] = (unsigned)((v.off + (long long)(ps * 32 + kl) * v.ld) * 2);
@@ -212,24 +226,30 @@ struct PPOperand {
         voff[0][1] = (unsigned)((v.off + (long long)b1 * v.batch_stride + (long long)t1 * v.ld) * 2);
     }
     // unit H of the K tile whose first k is k0 -> LDS at byte address lds (wave-uniform part added here)
-    template <int H>
+    // PS: -1 both LDS-DMA instructions of the unit, 0 / 1 one of them
+    // The K tile that crosses K (only when K % 64 != 0) takes a branch of its own: on every other tile an instruction is its m0 write and
+    // the load - the selects of the masked form, executed for every tile, cost the K loop more than the loads themselves (round 5).
+    template <int H, int PS = -1>
     __device__ __forceinline__ void issue(unsigned lds, int k0, int K, int wave_u) const {
-        const bool tail = k0 + BK > K;                // uniform: only the last K tile of an operand pays for the selects
-        const int krow = wave_u * 4 + ((int)(threadIdx.x & 63) >> 4);       // RC: my k-row inside a pass
-        if (!RC) {
+        const bool tail = k0 + BK > K;                // uniform
+        const unsigned ldsw = lds + (unsigned)wave_u * 1024u;          // (ps * 64 + wave * 8) rows x 128 B = (ps * 32 + wave * 4) k-rows x 256 B
+        constexpr int NPS = (!RC && IS_A && MT == 192 && H == 1) ? 1 : 2;      // the 64-row unit: one pass
+        if (__builtin_expect(tail, 0)) {
+            asm volatile("" ::: "memory");            // (keeps this a branch: no if-conversion into the common path)
+            const int krow = wave_u * 4 + ((int)(threadIdx.x & 63) >> 4);       // RC: my k-row inside a pass
 #pragma unroll
-            for (int ps = 0; ps < ((IS_A && MT == 192 && H == 1) ? 1 : 2); ++ps) {      // the 64-row unit: one pass
-                unsigned vo = voff[H][ps];
-                if (tail && k0 + kc >= K) vo = PP_OOB;
-                pp_dma16(rsrc, vo, soff, lds + (ps * 64 + wave_u * 8) * 128);
+            for (int ps = 0; ps < NPS; ++ps) {
+                if (PS >= 0 && ps != PS) continue;
+                unsigned vo = RC ? voff[0][ps] + voff[1][H] : voff[H][ps];       // RC: the column part is PP_OOB when out of range: the sum stays >= 2^31
+                if (RC ? (k0 + ps * 32 + krow >= K) : (k0 + kc >= K)) vo = PP_OOB;
+                pp_dma16(rsrc, vo, soff, ldsw + ps * 8192);
             }
-        } else {
+            return;
+        }
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {
-                unsigned vo = voff[0][ps] + voff[1][H];       // column part is PP_OOB when out of range: the sum stays >= 2^31
-                if (tail && k0 + ps * 32 + krow >= K) vo = PP_OOB;
-                pp_dma16(rsrc, vo, soff, lds + (ps * 32 + wave_u * 4) * 256);
-            }
+        for (int ps = 0; ps < NPS; ++ps) {
+            if (PS >= 0 && ps != PS) continue;
+            pp_dma16(rsrc, RC ? voff[0][ps] + voff[1][H] : voff[H][ps], soff, ldsw + ps * 8192);
         }
     }
     __device__ __forceinline__ void advance() {
@@ -250,17 +270,18 @@ struct PPIssue {
     PPDiv dv;
     int q, qstep;
     int kt, nk, k0, seq, wave_u, K;
+    int ahead;              // free-running schedule: calls for kinds 2 / 3 that were served early (gemm_fr.hip); 0 elsewhere
     int g;                  // GRP: problem of the item being issued
     unsigned lds0;          // LDS byte address of the stage buffers
-    bool live;
+    int live;               // (an int: a bool carried around the K loop becomes a lane mask that every issue point converts back)
 
     __device__ __forceinline__ void load_item(int tid) {
         if constexpr (GRP) {
-            live = q < pp_group().W;
+            live = q < pp_group().W ? 1 : 0;
             if (!live) return;
             while (q >= pp_group().wstart[g + 1]) ++g;          // items are handed out in increasing order
         } else {
-            live = q < dv.W;
+            live = q < dv.W ? 1 : 0;
             if (!live) return;
         }
         const SmxGemmParams& p = pp_kernarg_g<GRP>(g);
@@ -280,15 +301,18 @@ struct PPIssue {
         b.init(reinterpret_cast<const bf16_t*>(p.B) + it.zb, p.b, it.n0, p.N, k0, tid);
     }
     // KIND: 0 AH0, 1 BH0, 2 BH1, 3 AH1 (then move to the next K tile).  Returns false when the stream has ended.
-    template <int KIND, bool FREEZE = false>       // FREEZE (ablation builds): every K tile re-reads the item's first one
+    // FREEZE (ablation builds): every K tile re-reads the item's first one.  PS: see PPOperand::issue (the stream moves on with PS = -1 / 1)
+    template <int KIND, bool FREEZE = false, int PS = -1>
     __device__ __forceinline__ bool issue(int tid) {
+        if (MT == 192 && KIND >= 2 && ahead) { --ahead; return true; }          // (the 256-row forms have no register to spare for it)
         if (!live) return false;
         const unsigned st = lds0 + (unsigned)(seq & 1) * PP_STAGE;
-        if (KIND == 0) a.template issue<0>(st + 0 * PP_UNIT, k0, K, wave_u);
-        else if (KIND == 1) b.template issue<0>(st + 2 * PP_UNIT, k0, K, wave_u);
-        else if (KIND == 2) b.template issue<1>(st + 3 * PP_UNIT, k0, K, wave_u);
+        if (KIND == 0) a.template issue<0, PS>(st + 0 * PP_UNIT, k0, K, wave_u);
+        else if (KIND == 1) b.template issue<0, PS>(st + 2 * PP_UNIT, k0, K, wave_u);
+        else if (KIND == 2) b.template issue<1, PS>(st + 3 * PP_UNIT, k0, K, wave_u);
         else {
-            a.template issue<1>(st + 1 * PP_UNIT, k0, K, wave_u);
+            a.template issue<1, PS>(st + 1 * PP_UNIT, k0, K, wave_u);
+            if (PS == 0) return true;
             ++seq;
             if (++kt == nk) {
                 q += qstep;
@@ -395,6 +419,18 @@ __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
     return !(m & 7) && !(p.N & 7);
 }
 
+// Memory-side lane layout of the bf16 classes (round 5, tools/lab/st_lab.hip).  The accumulators give lane = row + 16 * chunk (a quad of
+// lanes = four ROWS, 16 bytes each): a CU issues such a 16-B-per-lane access at ~17 B/clk whether it is a store or a load, against 64 B/clk
+// when every quad of lanes covers 64 contiguous bytes.  So the packed outputs (and the side inputs) cross the lanes once through
+// ds_bpermute_b32 - no LDS memory - between that layout and lane = 4 * row + chunk, in which all 16-B global accesses are made.
+#ifndef SMX_EPI_PERM
+#define SMX_EPI_PERM 0
+#endif
+__device__ __forceinline__ uint4 pp_lane_perm(uint4 v, int src4) {          // every lane takes the 16 bytes of lane src4 / 4
+    return make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)v.x), (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)v.y),
+                      (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)v.z), (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)v.w));
+}
+
 template <int EPI, bool GRP = false, int NB = 8, bool BSW = false>
 __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0, int nw0, int n0, const char* bias_lds,
                                                  long long zc, long long ze, int lane, int gi = 0) {
@@ -402,6 +438,10 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
     const int i16 = lane & 15, g = lane >> 4;
     const bool sw = BSW && (g & 1);
     const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
+    constexpr bool PERM = SMX_EPI_PERM && EPI != PP_EPI_F32;
+    const int rm = PERM ? (lane >> 2) : i16;          // memory side: my row inside a 16-row block ...
+    const int nm = nw0 + (PERM ? (lane & 3) : g) * 8; // ... and my first column
+    const int to_mem = ((lane >> 2) + 16 * (lane & 3)) << 2, from_mem = (4 * i16 + g) << 2;      // ds_bpermute source lanes (x 4)
     // bias: the item's 256-column slice was put into LDS by an LDS-DMA issued when the item started (zeros beyond N)
     float bs[2][8];
 #pragma unroll
@@ -427,7 +467,13 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
     // activation derivative, no mask regeneration there); same arithmetic as epilogue_staged_fast<4 / 5> of the 128-family kernels
     const bool saved = (EPI == PP_EPI_ACT || EPI == PP_EPI_ACTGRAD) && (p.act & SMX_ACT_SAVE_GRAD);
     const int act = p.act & 0xff;
-    constexpr int GA = (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || NB % 4) ? 2 : 4;   // row blocks per group (x 2 halves = pieces in registers at once)
+#ifndef SMX_EPI_GA
+#define SMX_EPI_GA 0
+#endif
+    // row blocks per group (x 2 halves = pieces in registers at once)
+    PP_STAMP(40);
+    constexpr int GA = (SMX_EPI_GA && (EPI == PP_EPI_LINEAR || EPI == PP_EPI_ACTGRAD) && NB % (SMX_EPI_GA ? SMX_EPI_GA : 1) == 0) ? SMX_EPI_GA
+                       : (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || NB % 4) ? 2 : 4;
 #pragma unroll
     for (int grp = 0; grp < NB / GA; ++grp) {
         long long cb[GA], eb[GA];
@@ -437,14 +483,15 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
 #pragma unroll
         for (int a = 0; a < GA; ++a) {
             const int a8 = grp * GA + a;
-            const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + i16;
+            const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + rm;
             rok[a] = m < p.M;
             const int mm = rok[a] ? m : 0;
-            cb[a] = zc + pp_view_off(p.c, mm, rrc) + nl;
-            eb[a] = (EPI == PP_EPI_F32) ? 0 : ze + pp_view_off(p.e, mm, rre) + nl;
+            cb[a] = zc + pp_view_off(p.c, mm, rrc) + nm;
+            eb[a] = (EPI == PP_EPI_F32) ? 0 : ze + pp_view_off(p.e, mm, rre) + nm;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                const bool ok = rok[a] && nl + ch * 32 < p.N;
+                const bool ok = rok[a] && nm + ch * 32 < p.N;
+                if (PERM) side[a][ch] = make_uint4(0u, 0u, 0u, 0u);          // (lanes outside the output still take part in the lane exchange)
                 if (EPI == PP_EPI_ACTGRAD) {
                     if (ok) side[a][ch] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + eb[a] + ch * 32);
                 } else if (EPI == PP_EPI_LINEAR) {
@@ -472,6 +519,13 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                         asm volatile("" : "+v"(accum[a][ch][h].x), "+v"(accum[a][ch][h].y), "+v"(accum[a][ch][h].z),
                                      "+v"(accum[a][ch][h].w));
             }
+        if (grp == 0) PP_STAMP(41);
+        if (PERM && (EPI == PP_EPI_ACTGRAD || (EPI == PP_EPI_LINEAR && has_res))) {
+#pragma unroll
+            for (int a = 0; a < GA; ++a)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) side[a][ch] = pp_lane_perm(side[a][ch], from_mem);
+        }
         // all the arithmetic of the group first (independent chains the compiler can interleave: the inline-asm stores
         // are ordering points), results packed in registers, then the stores back to back
         uint4 outv[GA][2], auxv[EPI == PP_EPI_ACT ? GA : 1][2];
@@ -538,11 +592,22 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                 outv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
             }
         }
+        if (grp == 0) PP_STAMP(42);
+        if (PERM) {
+#pragma unroll
+            for (int a = 0; a < GA; ++a)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    outv[a][ch] = pp_lane_perm(outv[a][ch], to_mem);
+                    if (EPI == PP_EPI_ACT) auxv[EPI == PP_EPI_ACT ? a : 0][ch] = pp_lane_perm(auxv[EPI == PP_EPI_ACT ? a : 0][ch], to_mem);
+                }
+        }
+        if (grp == 0) PP_STAMP(43);
 #pragma unroll
         for (int a = 0; a < GA; ++a)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                if (!(rok[a] && nl + ch * 32 < p.N)) continue;
+                if (!(rok[a] && nm + ch * 32 < p.N)) continue;
                 if (EPI == PP_EPI_F32) {
                     float* c = reinterpret_cast<float*>(p.C) + cb[a] + ch * 32;
                     st_b128(c, make_uint4(__float_as_uint(outf[a][ch][0].x), __float_as_uint(outf[a][ch][0].y),
@@ -554,6 +619,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                 if (EPI == PP_EPI_ACT && p.aux_out) st_b128(reinterpret_cast<bf16_t*>(p.aux_out) + eb[a] + ch * 32, auxv[a][ch]);
                 st_b128(reinterpret_cast<bf16_t*>(p.C) + cb[a] + ch * 32, outv[a][ch]);
             }
+        if (grp == 0) PP_STAMP(44);
     }
 }
 

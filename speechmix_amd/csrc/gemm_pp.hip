@@ -110,7 +110,7 @@ __device__ __forceinline__ void pp_kernel_body(const KARG& karg) {
     is.dv.init(p, ntm, ntn);
     is.g = 0;
     is.q = blockIdx.x; is.qstep = gridDim.x;
-    is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0;
+    is.seq = 0; is.kt = 0; is.nk = 0; is.k0 = 0; is.ahead = 0;
     is.wave_u = __builtin_amdgcn_readfirstlane(wave);
     is.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     is.K = p.K;
