@@ -424,7 +424,7 @@ __device__ __forceinline__ bool pp_views_aligned(const SmxGemmParams& p) {
 // when every quad of lanes covers 64 contiguous bytes.  So the packed outputs (and the side inputs) cross the lanes once through
 // ds_bpermute_b32 - no LDS memory - between that layout and lane = 4 * row + chunk, in which all 16-B global accesses are made.
 #ifndef SMX_EPI_PERM
-#define SMX_EPI_PERM 0
+#define SMX_EPI_PERM 1
 #endif
 __device__ __forceinline__ uint4 pp_lane_perm(uint4 v, int src4) {          // every lane takes the 16 bytes of lane src4 / 4
     return make_uint4((unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)v.x), (unsigned)__builtin_amdgcn_ds_bpermute(src4, (int)v.y),
@@ -438,7 +438,9 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
     const int i16 = lane & 15, g = lane >> 4;
     const bool sw = BSW && (g & 1);
     const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
-    constexpr bool PERM = SMX_EPI_PERM && EPI != PP_EPI_F32;
+    // (where it pays: the linear class; the 192-row form of the data-gradient class - the activation class is VALU-bound, the 256-row forms of
+    // the other two have no registers left for the exchange)
+    constexpr bool PERM = SMX_EPI_PERM && (EPI == PP_EPI_LINEAR || (EPI == PP_EPI_ACTGRAD && NB == 6));
     const int rm = PERM ? (lane >> 2) : i16;          // memory side: my row inside a 16-row block ...
     const int nm = nw0 + (PERM ? (lane & 3) : g) * 8; // ... and my first column
     const int to_mem = ((lane >> 2) + 16 * (lane & 3)) << 2, from_mem = (4 * i16 + g) << 2;      // ds_bpermute source lanes (x 4)
@@ -459,9 +461,22 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
     const unsigned th = smx_thresh24(p.drop_p);
     const float inv_keep = 1.0f / (1.0f - p.drop_p);
     const bool drop = p.drop_p > 0.f;
-    const float rrc = 1.0f / (float)max(p.c.rows_per_batch, 1), rre = 1.0f / (float)max(p.e.rows_per_batch, 1);
+    // The views, sizes and pointers are taken out of the parameter block ONCE: behind every inline-asm store (a memory clobber) the compiler
+    // re-reads whatever it still addresses through `p` - a scalar load and its wait per row group (round 5 timeline: 0.5 us of 1.2 per group).
+    const SmxRowView vc = p.c, ve = p.e;
+    const int pM = p.M, pN = p.N;
+    const float alpha = p.alpha;
+    char* const pC = reinterpret_cast<char*>(p.C);
+    const bf16_t* const p_side = reinterpret_cast<const bf16_t*>(EPI == PP_EPI_ACTGRAD ? p.aux_in : p.resid);
+    bf16_t* const p_aux = reinterpret_cast<bf16_t*>(p.aux_out);
+    const float rrc = __builtin_amdgcn_rcpf((float)max(vc.rows_per_batch, 1)), rre = __builtin_amdgcn_rcpf((float)max(ve.rows_per_batch, 1));
     const bool has_res = EPI == PP_EPI_LINEAR && p.resid;
     const bool has_acc = EPI == PP_EPI_F32 && p.atomic == 2;
+    const bool need_e = EPI == PP_EPI_ACT || EPI == PP_EPI_ACTGRAD || has_res;
+    // the seed + the step key (one scalar load, dropout launches only); the ACTGRAD class reads it where it hashes - which it does only without
+    // the saved derivative - because one more value held across its groups spills in the 256-row form
+    const unsigned dseed_h = (EPI != PP_EPI_ACTGRAD && drop) ? smx_dseed(p.drop_p, p.drop_seed) : 0u;
+#define PP_DSEED() (EPI == PP_EPI_ACTGRAD ? smx_dseed(p.drop_p, p.drop_seed) : dseed_h)
     // SMX_ACT_SAVE_GRAD (round 3): the side tensor holds the epilogue's local derivative act'(pre) x dropout multiplier - written by
     // the forward ACT class in place of the pre-activation copy, multiplied in by the data gradient's ACTGRAD class (no
     // activation derivative, no mask regeneration there); same arithmetic as epilogue_staged_fast<4 / 5> of the 128-family kernels
@@ -470,10 +485,13 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
 #ifndef SMX_EPI_GA
 #define SMX_EPI_GA 0
 #endif
+#ifndef SMX_EPI_AG8_GA          // row blocks per group of the 256-row data-gradient class: 4 spills 8 - 12 bytes there (lab switch)
+#define SMX_EPI_AG8_GA 2
+#endif
     // row blocks per group (x 2 halves = pieces in registers at once)
     PP_STAMP(40);
     constexpr int GA = (SMX_EPI_GA && (EPI == PP_EPI_LINEAR || EPI == PP_EPI_ACTGRAD) && NB % (SMX_EPI_GA ? SMX_EPI_GA : 1) == 0) ? SMX_EPI_GA
-                       : (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || NB % 4) ? 2 : 4;
+                       : (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || (EPI == PP_EPI_ACTGRAD && NB == 8 && SMX_EPI_AG8_GA == 2) || NB % 4) ? 2 : 4;
 #pragma unroll
     for (int grp = 0; grp < NB / GA; ++grp) {
         long long cb[GA], eb[GA];
@@ -484,21 +502,21 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
         for (int a = 0; a < GA; ++a) {
             const int a8 = grp * GA + a;
             const int m = mw0 + (a8 >> 2) * 64 + (a8 & 3) * 16 + rm;
-            rok[a] = m < p.M;
+            rok[a] = m < pM;
             const int mm = rok[a] ? m : 0;
-            cb[a] = zc + pp_view_off(p.c, mm, rrc) + nm;
-            eb[a] = (EPI == PP_EPI_F32) ? 0 : ze + pp_view_off(p.e, mm, rre) + nm;
+            cb[a] = zc + pp_view_off(vc, mm, rrc) + nm;
+            eb[a] = need_e ? ze + pp_view_off(ve, mm, rre) + nm : 0;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                const bool ok = rok[a] && nm + ch * 32 < p.N;
+                const bool ok = rok[a] && nm + ch * 32 < pN;
                 if (PERM) side[a][ch] = make_uint4(0u, 0u, 0u, 0u);          // (lanes outside the output still take part in the lane exchange)
                 if (EPI == PP_EPI_ACTGRAD) {
-                    if (ok) side[a][ch] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux_in) + eb[a] + ch * 32);
+                    if (ok) side[a][ch] = *reinterpret_cast<const uint4*>(p_side + eb[a] + ch * 32);
                 } else if (EPI == PP_EPI_LINEAR) {
-                    if (has_res && ok) side[a][ch] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.resid) + eb[a] + ch * 32);
+                    if (has_res && ok) side[a][ch] = *reinterpret_cast<const uint4*>(p_side + eb[a] + ch * 32);
                 } else if (EPI == PP_EPI_F32) {
                     if (has_acc && ok) {
-                        const float* c = reinterpret_cast<const float*>(p.C) + cb[a] + ch * 32;
+                        const float* c = reinterpret_cast<const float*>(pC) + cb[a] + ch * 32;
                         accum[a][ch][0] = *reinterpret_cast<const float4*>(c);
                         accum[a][ch][1] = *reinterpret_cast<const float4*>(c + 4);
                     }
@@ -548,7 +566,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], p.alpha, bs[ch][e]);
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(x[e], alpha, bs[ch][e]);
                 if (EPI == PP_EPI_F32) {
                     if (has_acc) {
                         x[0] += accum[a][ch][0].x; x[1] += accum[a][ch][0].y; x[2] += accum[a][ch][0].z; x[3] += accum[a][ch][0].w;
@@ -560,7 +578,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                 }
                 if (EPI == PP_EPI_ACT) {
                     if (saved) {
-                        auxv[a][ch] = act_fwd_grad_drop8(x, act, drop, smx_dseed(p.drop_p, p.drop_seed), (unsigned)((long long)m * p.N + n + zc), th, inv_keep);
+                        auxv[a][ch] = act_fwd_grad_drop8(x, act, drop, PP_DSEED(), (unsigned)((long long)m * pN + n + zc), th, inv_keep);
                     } else {
                         auxv[a][ch] = make_uint4(pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7]));
                         act_fwd8(x, act);
@@ -579,8 +597,8 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
                     }
                 }
                 if (drop && !saved) {
-                    const unsigned idx = (unsigned)((long long)m * p.N + n + zc);
-                    smx_drop_mul8(smx_dseed(p.drop_p, p.drop_seed), idx, th, inv_keep, x);        // (+ the step key: a scalar load on the dropout path only)
+                    const unsigned idx = (unsigned)((long long)m * pN + n + zc);
+                    smx_drop_mul8(PP_DSEED(), idx, th, inv_keep, x);
                 }
                 if (EPI == PP_EPI_LINEAR && has_res) {
                     const uint4 u = side[a][ch];
@@ -607,19 +625,19 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
         for (int a = 0; a < GA; ++a)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                if (!(rok[a] && nm + ch * 32 < p.N)) continue;
+                if (!(rok[a] && nm + ch * 32 < pN)) continue;
                 if (EPI == PP_EPI_F32) {
-                    float* c = reinterpret_cast<float*>(p.C) + cb[a] + ch * 32;
+                    float* c = reinterpret_cast<float*>(pC) + cb[a] + ch * 32;
                     st_b128(c, make_uint4(__float_as_uint(outf[a][ch][0].x), __float_as_uint(outf[a][ch][0].y),
                                           __float_as_uint(outf[a][ch][0].z), __float_as_uint(outf[a][ch][0].w)));
                     st_b128(c + 4, make_uint4(__float_as_uint(outf[a][ch][1].x), __float_as_uint(outf[a][ch][1].y),
                                               __float_as_uint(outf[a][ch][1].z), __float_as_uint(outf[a][ch][1].w)));
                     continue;
                 }
-                if (EPI == PP_EPI_ACT && p.aux_out) st_b128(reinterpret_cast<bf16_t*>(p.aux_out) + eb[a] + ch * 32, auxv[a][ch]);
-                st_b128(reinterpret_cast<bf16_t*>(p.C) + cb[a] + ch * 32, outv[a][ch]);
+                if (EPI == PP_EPI_ACT && p_aux) st_b128(p_aux + eb[a] + ch * 32, auxv[a][ch]);
+                st_b128(reinterpret_cast<bf16_t*>(pC) + cb[a] + ch * 32, outv[a][ch]);
             }
         if (grp == 0) PP_STAMP(44);
     }
 }
-
+#undef PP_DSEED
