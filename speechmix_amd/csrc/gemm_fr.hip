@@ -146,7 +146,7 @@ __device__ __forceinline__ void fr_kernel_body() {
             all &= is.template issue<3>(tid);
             is.ahead = 2;
             if (!all) PP_WAITV(0);
-            else if constexpr (!A_RC) PP_WAITV(7);          // (the 64-row A unit is one instruction)
+            else if constexpr (!A_RC && MT == 192) PP_WAITV(7);          // (the 64-row A unit is one instruction)
             else PP_WAITV(8);
         } else {
             if (all) PP_WAITV(4);

@@ -41,6 +41,10 @@ __device__ __forceinline__ pp_rsrc_t pp_make_rsrc(const void* base) {
 }
 // 16 B per lane: LDS[m0 + lane * 16] = mem[rsrc.base + soff + voff]  (zeros when voff >= num_records)
 __device__ __forceinline__ void pp_dma16(pp_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_wave_base) {
+    // (the descriptor is uniform by construction; said again here because a descriptor the register allocator parked in vector registers
+    // reaches the "s" operand as a vector register - an assembler error in the busiest instantiations)
+    rsrc[0] = __builtin_amdgcn_readfirstlane(rsrc[0]); rsrc[1] = __builtin_amdgcn_readfirstlane(rsrc[1]);
+    rsrc[2] = __builtin_amdgcn_readfirstlane(rsrc[2]); rsrc[3] = __builtin_amdgcn_readfirstlane(rsrc[3]);
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %0, %2 offen lds"
                  :: "s"(rsrc), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(soff)),
                     "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory");
