@@ -169,7 +169,6 @@ struct PPOperand {
     unsigned soff;          // scalar byte offset of the current K tile
     unsigned sstep;         // its increment per K tile
     unsigned voff[2][2];    // KC: [half][pass] byte offset of my (row, chunk);  RC: [0][pass] = my k-row, [1][half] = my columns
-    int kc;                 // KC: first k of my chunk inside a K tile;  RC: my k-row inside a K tile (pass 0)
     int rt[1], rb[1];       // RC through a batched view (VIEW): my pass-0 k-row as (row inside batch, batch); pass 1 = +32 rows
     int rpb;                // RC + VIEW: rows per batch of the view
 
@@ -182,7 +181,7 @@ struct PPOperand {
     }
     __device__ __forceinline__ void init(const bf16_t* b, const SmxRowView& v, int row0, int nrows, int k0, int tid) {
         rsrc = pp_make_rsrc(b);
-        const float rrpb = 1.0f / (float)max(v.rows_per_batch, 1);
+        const float rrpb = __builtin_amdgcn_rcpf((float)max(v.rows_per_batch, 1));          // (pp_fdiv repairs the last place)
         const int lane = tid & 63, wave = tid >> 6;
         if (!RC) {
             soff = __builtin_amdgcn_readfirstlane((unsigned)k0 * 2u);          // (uniform: kept in a scalar register)
@@ -193,14 +192,12 @@ struct PPOperand {
                 for (int ps = 0; ps < 2; ++ps) {
                     const int hr = ps * 64 + wave * 8 + (lane >> 3);
                     const int c = (lane & 7) ^ (IS_A ? ((hr >> 1) & 7) : pp_bswz(hr));
-                    kc = c * 8;
                     const int gr = grow(h, hr);
                     const int r = row0 + gr;
                     voff[h][ps] = (gr >= 0 && r < nrows) ? (unsigned)(pp_view_off(v, r, rrpb) + c * 8) * 2u : PP_OOB;
                 }
         } else {
             const int kl = wave * 4 + (lane >> 4), g16 = lane & 15;      // rc_swz(kl) is the same for both passes
-            kc = 0;                                                      // (RC recomputes its k-row from the lane id)
             const int hc = IS_A ? ((((g16 >> 1) ^ rc_swz(kl)) << 1) | (g16 & 1)) * 8 : (g16 ^ pp_rcb_swz(kl)) * 8;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -240,7 +237,11 @@ struct PPOperand {
         constexpr int NPS = (!RC && IS_A && MT == 192 && H == 1) ? 1 : 2;      // the 64-row unit: one pass
         if (__builtin_expect(tail, 0)) {
             asm volatile("" ::: "memory");            // (keeps this a branch: no if-conversion into the common path)
-            const int krow = wave_u * 4 + ((int)(threadIdx.x & 63) >> 4);       // RC: my k-row inside a pass
+            const int ln = (int)(threadIdx.x & 63);
+            const int krow = wave_u * 4 + (ln >> 4);       // RC: my k-row inside a pass
+            // KC: first k of my 16-B chunk inside a K tile (recomputed here, on the rare path, rather than held in a register across the K loop)
+            const int hr0 = wave_u * 8 + (ln >> 3);
+            const int kc = ((ln & 7) ^ (IS_A ? ((hr0 >> 1) & 7) : pp_bswz(hr0))) * 8;
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
                 if (PS >= 0 && ps != PS) continue;
@@ -301,8 +302,14 @@ struct PPIssue {
         k0 = it.ks0 * BK;
         nk = it.nk;                       // >= 1: the launcher rejects split counts that leave a slice empty
         kt = 0;
-        a.init(reinterpret_cast<const bf16_t*>(p.A) + it.za, p.a, it.m0, p.M, k0, tid);
-        b.init(reinterpret_cast<const bf16_t*>(p.B) + it.zb, p.b, it.n0, p.N, k0, tid);
+        // (both views and the sizes are read from the parameter block in one go: taken field by field where they are used, every group of
+        // scalar loads costs its own wait - and this runs inside a K tile, with all eight waves of the workgroup at the same point)
+        const SmxRowView va = p.a, vb = p.b;
+        const bf16_t* const pa = reinterpret_cast<const bf16_t*>(p.A);
+        const bf16_t* const pb = reinterpret_cast<const bf16_t*>(p.B);
+        const int pM = p.M, pN = p.N;
+        a.init(pa + it.za, va, it.m0, pM, k0, tid);
+        b.init(pb + it.zb, vb, it.n0, pN, k0, tid);
     }
     // KIND: 0 AH0, 1 BH0, 2 BH1, 3 AH1 (then move to the next K tile).  Returns false when the stream has ended.
     // FREEZE (ablation builds): every K tile re-reads the item's first one.  PS: see PPOperand::issue (the stream moves on with PS = -1 / 1)

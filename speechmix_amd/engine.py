@@ -1997,7 +1997,7 @@ class Engine:
                 if g is None:
                     g = torch.cuda.CUDAGraph()
                     try:
-                        with torch.cuda.graph(g, pool=stt["pool"]):
+                        with torch.cuda.graph(g, pool=stt["pool"], capture_error_mode=os.environ.get("SMX_CAPTURE_MODE", "thread_local")):          # (see graphs.StepGraphs._begin)
                             step(t)
                     except RuntimeError as e:          # capture refused (a runtime without graph support for some call): stay eager
                         import warnings

@@ -41,6 +41,7 @@ MODE = os.environ.get("SMX_STEP_GRAPHS", "auto")
 ENABLED = MODE != "0"
 WARM_STEPS = int(os.environ.get("SMX_GRAPH_WARM_STEPS", "3"))      # eager steps of a configuration before its capture
 TRIAL_STEPS = int(os.environ.get("SMX_GRAPH_TRIAL_STEPS", "3"))
+CAPTURE_MODE = os.environ.get("SMX_CAPTURE_MODE", "thread_local")          # hipStreamCaptureMode of the captures (see StepGraphs._begin)
 
 
 CaptureAbort = ops.CaptureAbort
@@ -93,7 +94,10 @@ class StepGraphs:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        g.capture_begin(pool=self.pool)
+        # thread_local: only THIS thread's calls are checked against the capture.  Under the default ("global") a hipEventQuery from any other
+        # thread while the capture is open fails with hipErrorStreamCaptureUnsupported - and torch.distributed's NCCL watchdog thread polls its
+        # work events every few hundred milliseconds: the process then dies in the watchdog (seen once in four runs of tests/test_gpu_dist_single.py)
+        g.capture_begin(pool=self.pool, capture_error_mode=CAPTURE_MODE)
         self._cur = g
 
     # ---- capture
@@ -110,7 +114,12 @@ class StepGraphs:
         self.uses_premask = training and getattr(eng, "_premask", None) is not None
         eng._ensure_gplan()
         torch.cuda.synchronize()
-        side = torch.cuda.Stream()
+        # ONE capture stream per engine, not one per capture: torch hands out its 32 pool streams round-robin, so a process that keeps asking
+        # for streams is eventually handed the very stream RCCL's process group launches on - and an event last recorded on a capturing stream
+        # cannot be queried from any thread, in any capture mode (tools/gpu_capture_query_probe.py)
+        side = getattr(eng, "_capture_stream", None)
+        if side is None:
+            side = eng._capture_stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         ops.CAPTURING = True
         eng._cap = self

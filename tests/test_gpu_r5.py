@@ -225,6 +225,41 @@ def test_graph_replayed_steps_with_an_optimizer_and_in_eval_mode():
     assert g2[-1]["graphed"] and not _compare(e2, g2, offs)
 
 
+def test_capture_tolerates_event_queries_from_another_thread():
+    """torch.distributed's NCCL watchdog thread polls its work events (hipEventQuery) every few hundred milliseconds.  Under the
+    default capture mode such a query from ANY thread while a capture is open fails with hipErrorStreamCaptureUnsupported - it killed
+    tools/gpu_dist_single.py once in four runs - so the step is captured thread-locally (graphs.StepGraphs._begin).  Here a thread
+    queries an event in a tight loop while steps are captured and replayed: no error in the thread, the capture succeeds."""
+    import threading
+    ev, s2 = torch.cuda.Event(), torch.cuda.Stream()
+    with torch.cuda.stream(s2):          # (like a collective's end event: recorded behind real work on a stream of its own)
+        torch.zeros(1 << 20, device=DEV).add_(1)
+        ev.record()
+    torch.cuda.synchronize()
+    stop, errors, polls = threading.Event(), [], [0]
+
+    def poll():
+        torch.cuda.set_device(0)
+        while not stop.is_set():
+            try:
+                ev.query()
+                polls[0] += 1
+            except Exception as e:          # noqa: BLE001
+                errors.append(repr(e))
+                return
+
+    t = threading.Thread(target=poll, daemon=True)
+    t.start()
+    try:
+        graph, _, r = _run_steps(True, 6)
+    finally:
+        stop.set()
+        t.join(10)
+    assert not errors, errors[:1]
+    assert polls[0] > 100
+    assert graph[-1]["graphed"] and r._graph_failures == 0
+
+
 def test_graph_replay_follows_new_inputs_and_falls_back_on_a_new_shape():
     """The graphs read static input tensors that every replay refills; another batch shape drops the captured chain and runs
     eagerly (then captures the new configuration after its warm-up)."""
