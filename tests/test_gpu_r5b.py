@@ -127,3 +127,59 @@ def test_two_ranks_on_one_gpu_with_the_replayed_step():
     assert d["n_gpus"] == 2 and d["host"]["step_graphs"] is True and d["host"]["graphs_per_step"] >= 20, d["host"]
     assert d.get("params_in_sync") is True, d
     assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 50
+
+
+def test_256_wide_gemm_kernels_match_the_128_kernel_bit_for_bit_on_ragged_shapes():
+    """The persistent 256-wide kernels (tr_mode 8 ping-pong, 12 / 13 free-running with 256 / 192-row tiles) against the 128 x 128 kernel
+    (tr_mode 1): same K order and the same epilogue arithmetic -> bit-identical outputs, for every epilogue class the step uses (bias +
+    residual, GELU with dropout and the pre-activation / the saved derivative as the second output, the two data-gradient classes
+    with a rows-contiguous weight, the fp32 weight gradient with a K split) on ragged M / N / K, each launch twice (the second one finds
+    the LDS stages, the kernarg cache and - round 5 - the lane-exchanged stores, the early-issued K tile and the tail K tile of K % 64 != 0
+    in a warm state).  A seeded excerpt of tools/gpu_gemm_fuzz.py (2 000 cases there, 36 here)."""
+    import random
+    from speechmix_amd import ops
+    from speechmix_amd.ops import ACT_GELU, view
+    dev = torch.device("cuda:0")
+    rng = random.Random(11)
+    torch.manual_seed(11)
+    kinds = ["fwd", "fwd_act", "fwd_saved", "dgrad", "dgrad_actgrad", "dgrad_saved", "wgrad"]
+    compared = 0
+    for case in range(36):
+        M = rng.choice([264, 1000, 4000, 7968, 15968]) + 8 * rng.randrange(0, 4)
+        N = 8 * rng.randrange(8, 400)
+        K = 8 * rng.randrange(4, 200)
+        kind = kinds[case % len(kinds)]
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        Wt = W.t().contiguous()
+        bias = torch.randn(N, device=dev) * 0.1
+        S = torch.randn(M, N, device=dev).bfloat16()
+        ref, split = None, rng.choice([1, 3])
+        for mode in (1, 8, 12, 13, 13):
+            try:
+                if kind == "wgrad":
+                    kst = (M + 63) // 64
+                    per = (kst + split - 1) // split
+                    sp = (kst + per - 1) // per
+                    G = torch.zeros(sp, N, K, dtype=torch.float32, device=dev)
+                    ops.gemm(S, A, G, N, K, M, ops.BF16, a_rc=True, b_rc=True, av=view(N), bv=view(K), out_f32=True, split_k=sp,
+                             split_stride=N * K if sp > 1 else 0, tr_mode=mode)
+                    res = (G,)
+                else:
+                    Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                    aux = torch.zeros_like(Y)
+                    kw = {"fwd": dict(bias=bias, resid=S, drop=(0.1, 4)), "fwd_act": dict(bias=bias, act=ACT_GELU, aux_out=aux, drop=(0.1, 5)),
+                          "fwd_saved": dict(bias=bias, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out=aux, drop=(0.1, 6)),
+                          "dgrad": dict(b_rc=True, bv=view(N), resid=S), "dgrad_actgrad": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU),
+                          "dgrad_saved": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU | ops.ACT_SAVE_GRAD)}[kind]
+                    ops.gemm(A, Wt if kw.get("b_rc") else W, Y, M, N, K, ops.BF16, tr_mode=mode, **kw)
+                    res = (Y, aux)
+            except RuntimeError:          # (a layout / class a kernel family does not instantiate: the launcher refuses, the tuner never offers it)
+                continue
+            if mode == 1:
+                ref = res
+            else:
+                compared += 1
+                for a_, b_ in zip(ref, res):
+                    assert torch.equal(a_, b_), (case, kind, M, N, K, mode, (a_.float() - b_.float()).abs().max().item())
+    assert compared >= 100, compared
