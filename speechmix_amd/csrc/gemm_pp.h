@@ -227,10 +227,9 @@ struct PPOperand {
         voff[0][1] = (unsigned)((v.off + (long long)b1 * v.batch_stride + (long long)t1 * v.ld) * 2);
     }
     // unit H of the K tile whose first k is k0 -> LDS at byte address lds (wave-uniform part added here)
-    // PS: -1 both LDS-DMA instructions of the unit, 0 / 1 one of them
     // The K tile that crosses K (only when K % 64 != 0) takes a branch of its own: on every other tile an instruction is its m0 write and
     // the load - the selects of the masked form, executed for every tile, cost the K loop more than the loads themselves (round 5).
-    template <int H, int PS = -1>
+    template <int H>
     __device__ __forceinline__ void issue(unsigned lds, int k0, int K, int wave_u) const {
         const bool tail = k0 + BK > K;                // uniform
         const unsigned ldsw = lds + (unsigned)wave_u * 1024u;          // (ps * 64 + wave * 8) rows x 128 B = (ps * 32 + wave * 4) k-rows x 256 B
@@ -244,7 +243,6 @@ struct PPOperand {
             const int kc = ((ln & 7) ^ (IS_A ? ((hr0 >> 1) & 7) : pp_bswz(hr0))) * 8;
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
-                if (PS >= 0 && ps != PS) continue;
                 unsigned vo = RC ? voff[0][ps] + voff[1][H] : voff[H][ps];       // RC: the column part is PP_OOB when out of range: the sum stays >= 2^31
                 if (RC ? (k0 + ps * 32 + krow >= K) : (k0 + kc >= K)) vo = PP_OOB;
                 pp_dma16(rsrc, vo, soff, ldsw + ps * 8192);
@@ -253,7 +251,6 @@ struct PPOperand {
         }
 #pragma unroll
         for (int ps = 0; ps < NPS; ++ps) {
-            if (PS >= 0 && ps != PS) continue;
             pp_dma16(rsrc, RC ? voff[0][ps] + voff[1][H] : voff[H][ps], soff, ldsw + ps * 8192);
         }
     }
@@ -312,18 +309,17 @@ struct PPIssue {
         b.init(pb + it.zb, vb, it.n0, pN, k0, tid);
     }
     // KIND: 0 AH0, 1 BH0, 2 BH1, 3 AH1 (then move to the next K tile).  Returns false when the stream has ended.
-    // FREEZE (ablation builds): every K tile re-reads the item's first one.  PS: see PPOperand::issue (the stream moves on with PS = -1 / 1)
-    template <int KIND, bool FREEZE = false, int PS = -1>
+    // FREEZE (ablation builds): every K tile re-reads the item's first one.
+    template <int KIND, bool FREEZE = false>
     __device__ __forceinline__ bool issue(int tid) {
         if (MT == 192 && KIND >= 2 && ahead) { --ahead; return true; }          // (the 256-row forms have no register to spare for it)
         if (!live) return false;
         const unsigned st = lds0 + (unsigned)(seq & 1) * PP_STAGE;
-        if (KIND == 0) a.template issue<0, PS>(st + 0 * PP_UNIT, k0, K, wave_u);
-        else if (KIND == 1) b.template issue<0, PS>(st + 2 * PP_UNIT, k0, K, wave_u);
-        else if (KIND == 2) b.template issue<1, PS>(st + 3 * PP_UNIT, k0, K, wave_u);
+        if (KIND == 0) a.template issue<0>(st + 0 * PP_UNIT, k0, K, wave_u);
+        else if (KIND == 1) b.template issue<0>(st + 2 * PP_UNIT, k0, K, wave_u);
+        else if (KIND == 2) b.template issue<1>(st + 3 * PP_UNIT, k0, K, wave_u);
         else {
-            a.template issue<1, PS>(st + 1 * PP_UNIT, k0, K, wave_u);
-            if (PS == 0) return true;
+            a.template issue<1>(st + 1 * PP_UNIT, k0, K, wave_u);
             ++seq;
             if (++kt == nk) {
                 q += qstep;
