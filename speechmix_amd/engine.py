@@ -12,6 +12,8 @@ fp32 straight into the FlatStore's flat gradient buffer (the thing RCCL all-redu
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 import math
 import os
 from typing import Dict, List, Optional
@@ -26,6 +28,7 @@ from .params import FlatStore
 
 _ACT = {"gelu": ACT_GELU, "relu": ACT_RELU}
 _WGRAD_GROUP = os.environ.get("SMX_WGRAD_GROUP", "1") != "0"
+_COLSUM_SIDE = os.environ.get("SMX_COLSUM_SIDE", "1") != "0"
 
 
 def _act_id(name):
@@ -251,6 +254,9 @@ class Engine:
             self._side_active = False
             self._head_ev = None
             ops.GEMM_CONCURRENT = False
+        if getattr(self, "_cs_pending", False):           # column sums launched beside a grouped weight gradient (_wg_flush)
+            torch.cuda.current_stream().wait_stream(self._cs_stream)
+            self._cs_pending = False
         if self.folds is not None:
             self.folds.flush()          # the stage's bias / LayerNorm gradients are complete before it is reported
         if self.stage_cb is not None or self._cap is not None:
@@ -575,7 +581,11 @@ class Engine:
             # deferred: the layer's weight gradients go out as ONE grouped launch when the layer's backward ends (_wg_flush);
             # dy and x are never written again (every backward output is a fresh tensor, saved activations are read-only)
             grp.append((dy, x, gw, N, K, M, av, bv, alpha))
-            if gb is not None:
+            csd = getattr(self, "_cs_defer", None)
+            if gb is not None and side is None and csd is not None:
+                # (speech encoder layers: the bias-gradient column sums go out beside the layer's grouped launch, _wg_flush)
+                csd.append((dy, gb, M, N, dy_ld or N, alpha))
+            elif gb is not None:
                 if side is not None:                     # (LM stage: the column sums stay on the second stream)
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream())
@@ -664,6 +674,11 @@ class Engine:
         on = _WGRAD_GROUP and self.dt == BF16 and (rows is None or os.environ.get("SMX_LM_WGRAD_GROUP", "0") == "1")
         self._wg_group = [] if on else None
         self._wg_rows = rows if on else None
+        # Column sums beside the grouped launch (SMX_COLSUM_SIDE=0: off): a layer's grouped weight gradient runs 216 work items on 256 CUs for
+        # ~250 us, and the bias gradients of its QKV and FFN1 Linears are two HBM-bound passes over 73 + 98 MB that used to sit in the
+        # data-gradient chain (17 + 15 us per layer).  They are collected here and launched on a stream of their own right before the grouped
+        # launch (_wg_flush), on the 40 CUs it leaves idle; _stage joins that stream before the stage's partial rows are folded.
+        self._cs_defer = [] if (on and rows is None and _COLSUM_SIDE and self.st.device.type == "cuda") else None
 
     def _wg_flush(self, side=None):
         """side: a HIP stream - the grouped launch (and its slab reduction) go there, behind everything the current stream has
@@ -671,6 +686,22 @@ class Engine:
         216 work items on 256 CUs - runs beside the next layer's data-gradient chain, which takes the 40 CUs it leaves idle)."""
         grp, self._wg_group = getattr(self, "_wg_group", None), None
         self._wg_rows = None
+        cs, self._cs_defer = getattr(self, "_cs_defer", None), None
+        if cs:
+            beside = bool(grp) and len(grp) > 1 and side is None
+            if beside:
+                if getattr(self, "_cs_stream", None) is None:
+                    self._cs_stream = torch.cuda.Stream()
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._cs_stream.wait_event(ev)
+            with (torch.cuda.stream(self._cs_stream) if beside else contextlib.nullcontext()):
+                for dy, gb, M, N, ld, alpha in cs:
+                    ops.colsum(dy, gb, M, N, ld, self.dt, alpha, folds=self.folds)
+            if beside:
+                for dy, *_ in cs:
+                    dy.record_stream(self._cs_stream)
+                self._cs_pending = True
         if not grp:
             return False
         if side is not None and len(grp) > 1:
@@ -1996,6 +2027,8 @@ class Engine:
                 g = stt["graphs"].get(t)
                 if g is None:
                     g = torch.cuda.CUDAGraph()
+                    gc_was = gc.isenabled()
+                    gc.disable()              # (no finaliser may run on a capturing thread: graphs.StepGraphs.capture)
                     try:
                         with torch.cuda.graph(g, pool=stt["pool"], capture_error_mode=os.environ.get("SMX_CAPTURE_MODE", "thread_local")):          # (see graphs.StepGraphs._begin)
                             step(t)
@@ -2012,6 +2045,9 @@ class Engine:
                         if bool(done.all()):
                             break
                         continue
+                    finally:
+                        if gc_was:
+                            gc.enable()
                     if stt["pool"] is None:
                         stt["pool"] = g.pool()
                     stt["graphs"][t] = g
