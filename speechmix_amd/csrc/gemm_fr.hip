@@ -210,9 +210,9 @@ __device__ __forceinline__ void fr_kernel_body() {
             ++seq;
         }
         // EARLY (192-row tiles; the 256-row forms spill with it): the last two units of the NEXT item's second K tile go out here, ahead of the
-        // epilogue, instead of in that item's first half step: they
-        // are first touches of new operand rows (HBM latency) and the item's first barrier used to wait for them ~0.5 us (round 5 timeline).  Their
-        // stage is free: nothing reads this item's last stage after the barrier inside its last tile.
+        // epilogue, instead of in that item's first half step: they are first touches of new operand rows (HBM latency) and the item's first
+        // barrier used to wait for them ~0.5 us (round 5 timeline).  Their stage is free: nothing reads this item's last stage after the
+        // barrier inside its last tile.
         if constexpr (EARLY) {
             is.template issue<2, SMX_FR_LAB == 3>(tid);
             is.template issue<3, SMX_FR_LAB == 3>(tid);
