@@ -79,6 +79,17 @@ class FoldTable(C.Structure):
     _fields_ = [("n", C.c_int), ("pad", C.c_int), ("e", FoldEntry * FOLD_MAX)]
 
 
+TR_MAX = 64
+
+
+class TrEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("tile0", C.c_int), ("tcols", C.c_int)]
+
+
+class TrTable(C.Structure):
+    _fields_ = [("n", C.c_int), ("tiles", C.c_int), ("e", TrEntry * TR_MAX)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p), ("lse", C.c_void_p),
                 ("bias", C.c_void_p), ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),

@@ -689,6 +689,7 @@ static void dma8_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
 
 int smx_gemm_pp(const SmxGemmParams& p, hipStream_t stream);   // gemm_pp.hip
 int smx_gemm_fr(const SmxGemmParams& p, hipStream_t stream);   // gemm_fr.hip
+int smx_gemm_ws(const SmxGemmParams& p, hipStream_t stream);   // gemm_ws.hip
 
 // ------------------------------------------------------------------------------------------------
 // fp32: simple 64x64x16 VALU tile kernel with fully generic operand addressing.
@@ -902,6 +903,7 @@ extern "C" int smx_gemm(const SmxGemmParams* pp, int dtype, hipStream_t stream) 
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.nbatch * p.split_k);
     if ((p.tr_mode & 255) == 8) return smx_gemm_pp(p, stream);        // 256 x 256, persistent ping-pong
     if ((p.tr_mode & 255) == 12 || (p.tr_mode & 255) == 13) return smx_gemm_fr(p, stream);       // 256 x 256 / 192 x 256, persistent free-running schedule
+    if ((p.tr_mode & 255) == 14) return smx_gemm_ws(p, stream);          // 192 x 256, twelve compute + four loader waves (gemm_ws.hip)
     if (p.tr_mode == 1 || p.tr_mode == 7) { if (grid.x > 1024) grid.x = 1024; p.tr_mode = 1; }   // persistent tile walk (4 WG/CU resident)
     if (p.tr_mode == 11) {    // 256 x 128 tiles, eight waves, two workgroups per CU (gemm_bf16_dma8_kernel)
         const bool flagged = (p.act & SMX_ACT_SAVE_GRAD) != 0;

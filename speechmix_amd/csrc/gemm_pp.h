@@ -84,6 +84,8 @@ __device__ __forceinline__ const SmxGemmGroup& pp_group() {
 
 // 4 B per lane: LDS[m0 + lane * 4] = mem[rsrc.base + voff]  (zeros beyond num_records)
 __device__ __forceinline__ void pp_dma4(pp_rsrc_t rsrc, unsigned voff, unsigned lds_wave_base) {
+    rsrc[0] = __builtin_amdgcn_readfirstlane(rsrc[0]); rsrc[1] = __builtin_amdgcn_readfirstlane(rsrc[1]);          // (as in pp_dma16)
+    rsrc[2] = __builtin_amdgcn_readfirstlane(rsrc[2]); rsrc[3] = __builtin_amdgcn_readfirstlane(rsrc[3]);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %0, 0 offen lds"
                  :: "s"(rsrc), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory");
 }
@@ -447,7 +449,7 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
     const int nl = nw0 + g * 8;                       // my first column (half 0); half 1 = + 32
     // (where it pays: the linear class; the 192-row form of the data-gradient class - the activation class is VALU-bound, the 256-row forms of
     // the other two have no registers left for the exchange)
-    constexpr bool PERM = SMX_EPI_PERM && (EPI == PP_EPI_LINEAR || (EPI == PP_EPI_ACTGRAD && NB == 6));
+    constexpr bool PERM = SMX_EPI_PERM && (EPI == PP_EPI_LINEAR || (EPI == PP_EPI_ACTGRAD && NB <= 6));
     const int rm = PERM ? (lane >> 2) : i16;          // memory side: my row inside a 16-row block ...
     const int nm = nw0 + (PERM ? (lane & 3) : g) * 8; // ... and my first column
     const int to_mem = ((lane >> 2) + 16 * (lane & 3)) << 2, from_mem = (4 * i16 + g) << 2;      // ds_bpermute source lanes (x 4)
@@ -497,7 +499,10 @@ __device__ __forceinline__ void pp_epilogue_fast(f32x4_t (&acc)[NB][4], int mw0,
 #endif
     // row blocks per group (x 2 halves = pieces in registers at once)
     PP_STAMP(40);
-    constexpr int GA = (SMX_EPI_GA && (EPI == PP_EPI_LINEAR || EPI == PP_EPI_ACTGRAD) && NB % (SMX_EPI_GA ? SMX_EPI_GA : 1) == 0) ? SMX_EPI_GA
+#ifndef SMX_WS_GA          // row blocks per group of the 128-register waves of gemm_ws.hip (NB == 4)
+#define SMX_WS_GA 1
+#endif
+    constexpr int GA = NB == 4 ? SMX_WS_GA : (SMX_EPI_GA && (EPI == PP_EPI_LINEAR || EPI == PP_EPI_ACTGRAD) && NB % (SMX_EPI_GA ? SMX_EPI_GA : 1) == 0) ? SMX_EPI_GA
                        : (EPI == PP_EPI_F32 || EPI == PP_EPI_ACT || (EPI == PP_EPI_ACTGRAD && NB == 8 && SMX_EPI_AG8_GA == 2) || NB % 4) ? 2 : 4;
 #pragma unroll
     for (int grp = 0; grp < NB / GA; ++grp) {

@@ -372,6 +372,73 @@ extern "C" int smx_fold_many(const SmxFoldTable* tp, hipStream_t stream) {
     SMX_CHECK_LAUNCH();
 }
 extern "C" int smx_sizeof_SmxFoldTable(void) { return (int)sizeof(SmxFoldTable); }
+// ---- batched 2-D transposes of 16-bit matrices (round 6) ----
+// dst[cols][rows] = src[rows][cols] for up to SMX_TR_MAX matrices per launch (rows, cols multiples of 8; 16-B accesses on both sides).
+// Used for the K-contiguous copies of the Linear weights that the data-gradient GEMMs read (engine.py `dgrad`): with W^T stored
+// [in][out] the data gradient is a (KC, KC) launch - 16-byte fragment reads instead of two transposing 8-byte reads per fragment
+// (K tile of the 256-wide kernels 1.18 -> 1.28 us with a rows-contiguous B, profiles/r05_fr_timeline.txt) - for one pass over the
+// weights per optimizer step (85 MB of the 470 MB of config 2: ~40 us).
+#define SMX_TR_MAX 64
+struct SmxTrEntry {
+    const unsigned short* src;
+    unsigned short* dst;
+    int rows, cols;
+    int tile0, tcols;          // first tile of this matrix in the launch; tiles per row of tiles
+};
+struct SmxTrTable {
+    int n, tiles;
+    SmxTrEntry e[SMX_TR_MAX];
+};
+__global__ __launch_bounds__(256) void transpose_many_kernel(SmxTrTable t) {
+    __shared__ unsigned short tile[64][72];          // (144-B rows: the 16-B row writes and the 2-B column reads both spread over the banks)
+    int lo = 0, hi = t.n - 1;                        // last entry whose first tile is <= my tile
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.e[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const SmxTrEntry& en = t.e[lo];
+    const int tl = blockIdx.x - en.tile0;
+    const int r0 = (tl / en.tcols) * 64, c0 = (tl % en.tcols) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int r = ps * 32 + (tid >> 3), c = (tid & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + r < en.rows && c0 + c < en.cols) v = *reinterpret_cast<const uint4*>(en.src + (long long)(r0 + r) * en.cols + c0 + c);
+        *reinterpret_cast<uint4*>(&tile[r][c]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int c = ps * 32 + (tid >> 3), r = (tid & 7) * 8;          // output row c0 + c, 8 consecutive source rows
+        if (c0 + c < en.cols && r0 + r < en.rows) {
+            union { uint4 v; unsigned short s[8]; } o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o.s[e] = tile[r + e][c];
+            *reinterpret_cast<uint4*>(en.dst + (long long)(c0 + c) * en.rows + r0 + r) = o.v;
+        }
+    }
+}
+extern "C" int smx_transpose_many(const SmxTrTable* tp, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!tp || tp->n < 0 || tp->n > SMX_TR_MAX) return SMX_EINVAL;
+    if (tp->n == 0) return SMX_OK;
+    SmxTrTable t = *tp;
+    int tiles = 0;
+    for (int i = 0; i < t.n; ++i) {
+        SmxTrEntry& e = t.e[i];
+        if (!e.src || !e.dst || e.rows <= 0 || e.cols <= 0 || (e.rows & 7) || (e.cols & 7) || ((size_t)e.src & 15) || ((size_t)e.dst & 15)) return SMX_EINVAL;
+        e.tile0 = tiles;
+        e.tcols = (e.cols + 63) / 64;
+        tiles += e.tcols * ((e.rows + 63) / 64);
+    }
+    t.tiles = tiles;
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(tiles), dim3(256), 0, stream, t);
+    SMX_CHECK_LAUNCH();
+}
+extern "C" int smx_sizeof_SmxTrTable(void) { return (int)sizeof(SmxTrTable); }
+extern "C" int smx_tr_max(void) { return SMX_TR_MAX; }
+
 extern "C" int smx_fold_max(void) { return SMX_FOLD_MAX; }
 
 // ---------------------------------------------------------------- cross entropy over the vocabulary
@@ -668,6 +735,7 @@ SMX_STEP_KEY_TU(misc)
 extern "C" int smx_step_key_addr_gemm(void**);
 extern "C" int smx_step_key_addr_gemm_pp(void**);
 extern "C" int smx_step_key_addr_gemm_fr(void**);
+extern "C" int smx_step_key_addr_gemm_ws(void**);
 extern "C" int smx_step_key_addr_norm(void**);
 extern "C" int smx_step_key_addr_attention(void**);
 struct SmxKeyAddrs { unsigned* a[8]; int n; };
@@ -682,7 +750,7 @@ extern "C" int smx_set_step_key(unsigned key, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess) return -5;
     dev &= 15;
     if (!done[dev]) {          // (first call per device: must not happen inside a stream capture - the engine sets a key eagerly first)
-        int (*fns[])(void**) = {smx_step_key_addr_misc, smx_step_key_addr_gemm, smx_step_key_addr_gemm_pp, smx_step_key_addr_gemm_fr,
+        int (*fns[])(void**) = {smx_step_key_addr_misc, smx_step_key_addr_gemm, smx_step_key_addr_gemm_pp, smx_step_key_addr_gemm_fr, smx_step_key_addr_gemm_ws,
                                 smx_step_key_addr_norm, smx_step_key_addr_attention};
         tab[dev].n = 0;
         for (auto fn : fns) {

@@ -37,6 +37,9 @@ def _act_id(name):
     return _ACT[name]
 
 
+WT_MODE = os.environ.get("SMX_DGRAD_WT", "1") != "0"      # data gradients read K-contiguous weight copies (Engine._wt)
+WT_MIN_M = int(os.environ.get("SMX_DGRAD_WT_MINM", "4096"))
+
 class HFHostRNG:
     """The host-side random streams HuggingFace draws from in train mode: legacy `np.random` for the SpecAugment spans
     (TF:models/wav2vec2/modeling_wav2vec2.py:139 `np.random.rand(1)`, :183 `np.random.choice`) and torch's CPU generator for
@@ -496,10 +499,49 @@ class Engine:
 
     def dgrad(self, dy, w, dx, M, N, K, resid=None, aux_in=None, act=ACT_NONE, av=None, bv=None, cv=None, ev=None,
               alpha=1.0, **kw):
-        """dx[M,K] = dy[M,N] @ w[N,K]   (w read rows-contiguous: no transposed weight copy)."""
+        """dx[M,K] = dy[M,N] @ w[N,K].  bf16 path, plain weights: the GEMM reads the K-contiguous copy w^T [K, N] (`_wt`), so that both
+        operands take the 16-byte fragment reads; otherwise w is read rows-contiguous in place."""
+        # (the activation-gradient class - FFN2's data gradient - keeps the in-place read: its saved-derivative epilogues are instantiated for
+        # the rows-contiguous layout only)
+        # (and only where the GEMM is long enough for the read to matter: at the decoder's M = 1 024 the copy costs what it saves)
+        wt = self._wt(w, N, K) if (bv is None and aux_in is None and M >= WT_MIN_M) else None
+        if wt is not None:
+            self._gemm(dy, wt, dx, M, K, N, av=av, bv=view(N), cv=cv, ev=ev, resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
+            return dx
         self._gemm(dy, w, dx, M, K, N, b_rc=True, av=av, bv=bv if bv is not None else view(K), cv=cv, ev=ev,
                    resid=resid, aux_in=aux_in, act=act, alpha=alpha, **kw)
         return dx
+
+    # ---- K-contiguous copies of the Linear weights for the data gradients (round 6) ----
+    # One persistent [K, N] tensor per weight view the data gradients have met, re-made by ONE batched transpose launch (per 64 weights)
+    # at the first data gradient after the compute copies changed: trainable weights after every optimizer step (FlatStore.wver),
+    # frozen ones only after a re-cast of the masters (FlatStore.hard_ver).  SMX_DGRAD_WT=0: off (the rows-contiguous reads of rounds 1-5).
+    def _wt(self, w, N, K):
+        if not WT_MODE or self.dt != BF16 or (N & 7) or (K & 7) or w.dtype != torch.bfloat16 or not w.is_contiguous():
+            return None
+        st = self.st
+        key = (w.data_ptr(), N, K)
+        tab = self.__dict__.setdefault("_wt_tab", {})
+        ent = tab.get(key)
+        if ent is None:
+            off = (w.data_ptr() - st.shadow.data_ptr()) // 2
+            if st.shadow is st.master or off < 0 or off + N * K > st.total:
+                return None          # not a view of the flat store (packed / temporary operands): read in place
+            if ops.CAPTURING:
+                raise ops.CaptureAbort("a data gradient met a weight without a transposed copy inside a stream capture")
+            name = st.name_at(off)
+            ent = tab[key] = {"src": w.view(N, K), "dst": torch.empty(K, N, dtype=w.dtype, device=w.device), "ver": -1,
+                              "trainable": name is None or st.requires_grad(name)}
+        want = st.wver if ent["trainable"] else st.hard_ver
+        if ent["ver"] != want:
+            jobs = []
+            for e in tab.values():          # every stale copy in the same launch (the first data gradient of a backward pays for all)
+                wv = st.wver if e["trainable"] else st.hard_ver
+                if e["ver"] != wv:
+                    jobs.append((e["src"], e["dst"]))
+                    e["ver"] = wv
+            ops.transpose_many(jobs)
+        return ent["dst"]
 
     def _slab_key(self):
         """Grow-only slab workspace, one per stream: a buffer that grows is replaced, and the replaced tensor must not go back

@@ -177,6 +177,7 @@ def _pp_applicable(p, dtype):
     return items >= 96                     # fewer work items than that cannot occupy the chip with one workgroup per CU
 
 
+WS_MODE = os.environ.get("SMX_GEMM_WS", "auto")       # wave-specialised 192x256 kernel (tr_mode 14, csrc/gemm_ws.hip): auto | 0
 FR_MODE = os.environ.get("SMX_GEMM_FR", "auto")       # free-running 256x256 schedule (tr_mode 12, csrc/gemm_fr.hip): auto | 0 | 1
 
 
@@ -209,7 +210,7 @@ _atexit.register(_bytes_log_save)
 
 
 def _launch(p, dtype):
-    if (p.tr_mode & 255) in (8, 12, 13) and pp_cus():
+    if (p.tr_mode & 255) in (8, 12, 13, 14) and pp_cus():
         p.tr_mode = (p.tr_mode & 0xffff) | (pp_cus() << 16)          # persistent grid cap (gemm_pp.hip)
     if _BYTES_LOG is not None and dtype == BF16:
         _BYTES_LOG.append(_gemm_bytes(p, dtype))
@@ -309,6 +310,8 @@ def _choose_mode(p, dtype):
             cands.append(12)
             if p.M >= 1024 and p.split_k == 1:          # 192 x 256 tiles: better quantisation of N = 768 / 2304 at 16 k rows
                 cands.append(13)
+                if WS_MODE != "0":                     # the same tile with twelve compute + four loader waves (csrc/gemm_ws.hip)
+                    cands.append(14)
     if _half_applicable(p, dtype):
         if HALF_MODE == "1":
             return 9
@@ -331,7 +334,7 @@ def _choose_mode(p, dtype):
             mode = min(times, key=lambda m: times[m] * (1.0 if m == 1 else _TUNE_MARGIN))      # ties go to the 128x128 kernel
             TUNE_LIVE_KEYS.append(key)
             if TUNE_LOG is not None:
-                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11), times.get(12), times.get(13)))
+                TUNE_LOG.append((key, times.get(1), times.get(8), mode, times.get(9), times.get(11), times.get(12), times.get(13), times.get(14)))
         _tuned_set(key, mode)
     return mode
 
@@ -593,6 +596,18 @@ class FoldQueue:
                 e.ws, e.dst = _ptr(ws) + 4 * off, _ptr(dst)
                 e.nrows, e.ncols, e.ld, e.alpha = nrows, ncols, ld, alpha
             L.check(L.lib().smx_fold_many(C.byref(t), _stream()), "smx_fold_many")
+
+
+def transpose_many(jobs):
+    """jobs: [(src [rows, cols], dst [cols, rows])] of 16-bit tensors (rows, cols multiples of 8) - one launch per 64 matrices."""
+    for i in range(0, len(jobs), L.TR_MAX):
+        chunk = jobs[i:i + L.TR_MAX]
+        t = L.TrTable()
+        t.n = len(chunk)
+        for j, (src, dst) in enumerate(chunk):
+            e = t.e[j]
+            e.src, e.dst, e.rows, e.cols = _ptr(src), _ptr(dst), src.shape[0], src.shape[1]
+        L.check(L.lib().smx_transpose_many(C.byref(t), _stream()), "smx_transpose_many")
 
 
 def norm_bwd(dy, x, dx, gamma, beta, mean, rstd, dgamma, dbeta, M, D, dtype, rms=False, act=ACT_NONE, dres=None,

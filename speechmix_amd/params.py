@@ -294,6 +294,10 @@ class FlatStore:
         self.shadow = self.master if compute_dtype == torch.float32 else torch.zeros(
             self.total, dtype=compute_dtype, device=self.device)
         self._fresh = False
+        # versions of the compute copies (engine.py keeps transposed copies of the Linear weights for the data gradients): `wver` moves
+        # whenever the trainable tensors' copies change (optimizer steps), `hard_ver` when every tensor's may have (a re-cast of the masters)
+        self.wver = 0
+        self.hard_ver = 0
         # True: parameters may be updated behind our back (torch optimizers, load_state_dict) -> the bf16
         # copies are re-cast at every forward.  The built-in flat optimizer keeps them fresh itself.
         self.external_updates = True
@@ -361,10 +365,27 @@ class FlatStore:
         from . import ops
         ops.cast_from_f32(self.master, self.shadow, self.total, ops.BF16)
         self._fresh = True
+        self.wver += 1
+        self.hard_ver += 1
         return True
 
     def mark_shadow_fresh(self):
+        """The fused optimizer has written masters and compute copies together."""
         self._fresh = True
+        self.wver += 1
+
+    def name_at(self, elem_off):
+        """Name of the tensor that holds element `elem_off` of the flat buffers (None: padding / outside)."""
+        import bisect
+        if not hasattr(self, "_starts"):
+            items = sorted((o, n, name) for name, (o, n, _) in self.offsets.items())
+            self._starts = [o for o, _, _ in items]
+            self._spans = items
+        i = bisect.bisect_right(self._starts, elem_off) - 1
+        if i < 0:
+            return None
+        o, n, name = self._spans[i]
+        return name if o <= elem_off < o + n else None
 
     def invalidate(self):
         self._fresh = False

@@ -1,0 +1,92 @@
+"""Round 6: the wave-specialised GEMM kernel (tr_mode 14, csrc/gemm_ws.hip), the batched weight transposes and the data gradients that
+read the K-contiguous weight copies (Engine._wt).  Linear layers of ref:speechmix/model.py:148 -> TF:models/wav2vec2/modeling_wav2vec2.py:466-572."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wave_specialised_gemm_matches_the_128_kernel_bit_for_bit():
+    """Twelve compute + four loader waves on 192 x 256 tiles against the 128 x 128 kernel: same K order, same epilogue arithmetic ->
+    bit-identical outputs for every epilogue class the step uses, on ragged M / N / K (K from 32: one-tile items; K % 64 != 0: the tail
+    tile; split-K slabs for the weight gradient), each launch twice (warm LDS stages / item records / bias slots)."""
+    from speechmix_amd import ops
+    from speechmix_amd.ops import ACT_GELU, view
+    dev = torch.device("cuda:0")
+    rng = random.Random(23)
+    torch.manual_seed(23)
+    kinds = ["fwd", "fwd_act", "fwd_saved", "dgrad", "dgrad_actgrad", "dgrad_saved", "wgrad", "fwd_plain"]
+    compared = 0
+    for case in range(40):
+        M = rng.choice([264, 1000, 4000, 7968, 15968]) + 8 * rng.randrange(0, 4)
+        N = 8 * rng.randrange(8, 400)
+        K = 8 * rng.randrange(4, 200)
+        kind = kinds[case % len(kinds)]
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        Wt = W.t().contiguous()
+        bias = torch.randn(N, device=dev) * 0.1
+        S = torch.randn(M, N, device=dev).bfloat16()
+        ref, split = None, rng.choice([1, 3])
+        for mode in (1, 14, 14):
+            try:
+                if kind == "wgrad":
+                    kst = (M + 63) // 64
+                    per = (kst + split - 1) // split
+                    sp = (kst + per - 1) // per
+                    G = torch.zeros(sp, N, K, dtype=torch.float32, device=dev)
+                    ops.gemm(S, A, G, N, K, M, ops.BF16, a_rc=True, b_rc=True, av=view(N), bv=view(K), out_f32=True, split_k=sp,
+                             split_stride=N * K if sp > 1 else 0, tr_mode=mode)
+                    res = (G,)
+                else:
+                    Y = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+                    aux = torch.zeros_like(Y)
+                    kw = {"fwd": dict(bias=bias, resid=S, drop=(0.1, 4)), "fwd_act": dict(bias=bias, act=ACT_GELU, aux_out=aux, drop=(0.1, 5)),
+                          "fwd_saved": dict(bias=bias, act=ACT_GELU | ops.ACT_SAVE_GRAD, aux_out=aux, drop=(0.1, 6)),
+                          "dgrad": dict(b_rc=True, bv=view(N), resid=S), "dgrad_actgrad": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU),
+                          "dgrad_saved": dict(b_rc=True, bv=view(N), aux_in=S, act=ACT_GELU | ops.ACT_SAVE_GRAD), "fwd_plain": dict()}[kind]
+                    ops.gemm(A, Wt if kw.get("b_rc") else W, Y, M, N, K, ops.BF16, tr_mode=mode, **kw)
+                    res = (Y, aux)
+            except RuntimeError:          # (a shape the kernel family refuses: the tuner never offers it)
+                continue
+            if mode == 1:
+                ref = res
+            else:
+                compared += 1
+                for a_, b_ in zip(ref, res):
+                    assert torch.equal(a_, b_), (case, kind, M, N, K, mode, (a_.float() - b_.float()).abs().max().item())
+    assert compared >= 70, compared
+
+
+def test_transpose_many_is_exact():
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    shapes = [(768, 768), (2304, 768), (768, 3072), (3072, 768), (8, 8), (72, 200), (1000, 24), (50264, 768)]
+    shapes = shapes * 9          # 72 matrices: two launches (64 per table)
+    jobs = [(torch.randn(r, c, device=dev).bfloat16(), torch.zeros(c, r, dtype=torch.bfloat16, device=dev)) for r, c in shapes]
+    ops.transpose_many(jobs)
+    for src, dst in jobs:
+        assert torch.equal(dst, src.t().contiguous()), src.shape
+
+
+def test_data_gradient_through_the_transposed_weight_copy_is_bit_identical():
+    """The same kernel (tr_mode forced) reading W rows-contiguous and W^T K-contiguous: identical operand values in the same K order."""
+    from speechmix_amd import ops
+    from speechmix_amd.ops import view
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    for (M, N, K) in [(15968, 2304, 768), (7968, 768, 768), (1024, 3072, 768), (4000, 768, 3072)]:
+        dy = torch.randn(M, N, device=dev).bfloat16()
+        w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        r = torch.randn(M, K, device=dev).bfloat16()
+        wt = torch.empty(K, N, dtype=torch.bfloat16, device=dev)
+        ops.transpose_many([(w, wt)])
+        for mode in (1, 13, 14):
+            a = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+            b = torch.zeros_like(a)
+            ops.gemm(dy, w, a, M, K, N, ops.BF16, b_rc=True, bv=view(K), resid=r, tr_mode=mode)
+            ops.gemm(dy, wt, b, M, K, N, ops.BF16, bv=view(N), resid=r, tr_mode=mode)
+            assert torch.equal(a, b), (M, N, K, mode)

@@ -101,7 +101,8 @@ def items(N, mt):
     return ((M + mt - 1) // mt) * ((N + 255) // 256)
 
 
-for mode, mt in ((13, 192), (12, 256)):
+MODES = [tuple(int(v) for v in m.split(":")) for m in os.environ.get("SMX_TL_MODES", "13:192,12:256").split(",")]
+for mode, mt in MODES:
     print(f"==== tr_mode {mode} ({mt} x 256 tiles)   {os.path.basename(os.environ.get('SMX_LIB', ''))}")
     run("QKV fwd      N 2304 K 768  bias", lambda: ops.gemm(x, wqkv, y3, M, 3 * d, d, ops.BF16, bias=bqkv, tr_mode=mode), items(3 * d, mt))
     run("QKV fwd      N 2304 K 768  plain", lambda: ops.gemm(x, wqkv, y3, M, 3 * d, d, ops.BF16, tr_mode=mode), items(3 * d, mt))
