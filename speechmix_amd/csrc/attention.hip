@@ -737,6 +737,7 @@ __global__ __launch_bounds__(256, U == 1 ? 2 : 1) void attn_bwd_dkv_bf16(SmxAttn
 }
 
 #include "attention_v2.h"
+#include "attention_v3.h"
 
 static bool attn_use_v1() {
     static const bool v1 = getenv("SMX_ATTN_V1") && getenv("SMX_ATTN_V1")[0] == '1';      // A/B switch: first-generation kernels
@@ -783,6 +784,11 @@ extern "C" int smx_attention_fwd(const SmxAttnParams* pp, int dtype, hipStream_t
         hipLaunchKernelGGL(attn_fwd_simple<bf16_t>, dim3((n + 63) / 64), dim3(64), 0, stream, p);
     } else if (dtype == SMX_BF16 && !attn_use_v1()) {
         if (p.drop_p > 0.f && (!p.mask_q || !p.mask_k)) return SMX_EINVAL;       // smx_attn_dropout_mask first
+        if (attn_v3_mode() == 2 && p.Tk <= 64 * A3_MAXT && p.Tq >= 128) {              // K / V of a head resident in LDS (attention_v3.h)
+            const int nt = (p.Tk + 63) / 64;
+            A3_DISPATCH(attn3_fwd, 8, p.Tq, nt, 0);          // (sixteen waves at 128 registers spill 84 - 200 bytes in the tile bodies)
+            SMX_CHECK_LAUNCH();
+        }
         const dim3 grid(((p.Tq + 63) / 64) * p.H * p.B);
         A2_DISPATCH(attn2_fwd, grid);
     } else if (dtype == SMX_BF16) {
@@ -824,8 +830,11 @@ extern "C" int smx_attention_bwd(const SmxAttnParams* pp, int dtype, hipStream_t
         if (!attn_use_v1()) {
             if (p.drop_p > 0.f && (!p.mask_q || !p.mask_k)) return SMX_EINVAL;
             const dim3 gq(((p.Tq + 63) / 64) * p.H * p.B), gk(((p.Tk + 63) / 64) * p.H * p.B);
-            A2_DISPATCH(attn2_dq, gq);
-            A2_DISPATCH(attn2_dkv, gk);
+            // resident-operand forms (attention_v3.h): dQ with the head's K / V in LDS, dK/dV with its Q / dO (+ lse / delta rows)
+            if ((attn_v3_mode() == 2 ? p.Tq >= 128 : attn_v3_mode() == 1 && p.Tq >= 384) && p.Tk <= 64 * A3_MAXT) A3_DISPATCH(attn3_dq, 8, p.Tq, (p.Tk + 63) / 64, 0);
+            else A2_DISPATCH(attn2_dq, gq);
+            if ((attn_v3_mode() == 2 ? p.Tk >= 128 : attn_v3_mode() == 1 && p.Tk >= 384) && p.Tq <= 64 * A3_MAXT) A3_DISPATCH(attn3_dkv, 8, p.Tk, (p.Tq + 63) / 64, (size_t)((p.Tq + 63) / 64) * 512);
+            else A2_DISPATCH(attn2_dkv, gk);
         } else {
             hipLaunchKernelGGL(attn_bwd_dq_bf16<1>, dim3((p.Tq + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);
             hipLaunchKernelGGL(attn_bwd_dkv_bf16<1>, dim3((p.Tk + 63) / 64, p.H, p.B), dim3(256), 0, stream, p);

@@ -90,3 +90,50 @@ def test_data_gradient_through_the_transposed_weight_copy_is_bit_identical():
             ops.gemm(dy, w, a, M, K, N, ops.BF16, b_rc=True, bv=view(K), resid=r, tr_mode=mode)
             ops.gemm(dy, wt, b, M, K, N, ops.BF16, bv=view(N), resid=r, tr_mode=mode)
             assert torch.equal(a, b), (M, N, K, mode)
+
+
+def _attn_case(B, H, Tq, Tk, causal, drop, klen, bias, seed):
+    import os
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    D, d = 64, H * 64
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    q = (torch.randn(B * Tq, d, generator=g) * 0.7).to(dev, torch.bfloat16)
+    kv = (torch.randn(B * Tk, 2 * d, generator=g) * 0.7).to(dev, torch.bfloat16)
+    do = torch.randn(B * Tq, d, generator=g).to(dev, torch.bfloat16)
+    kl = torch.tensor(klen, dtype=torch.int32, device=dev) if klen is not None else None
+    bs = (torch.randn(H, Tq, Tk, generator=g) * 0.5).to(dev) if bias else None
+    out = {}
+    for v3 in ("0", "1"):          # 0: tile-staged kernels, 1: resident-operand forward + backward
+        os.environ["SMX_ATTN_V3"] = v3
+        desc = ops.AttnDesc(B, H, Tq, Tk, D, causal, D ** -0.5, bias=bs, drop=drop, klen=kl)
+        desc.set("Q", q, 0, Tq * d, d); desc.set("K", kv, 0, Tk * 2 * d, 2 * d); desc.set("V", kv, d, Tk * 2 * d, 2 * d)
+        o = torch.zeros(B * Tq, d, dtype=torch.bfloat16, device=dev)
+        lse = torch.zeros(B * H * Tq, device=dev)
+        delta = torch.zeros(B * H * Tq, device=dev)
+        dq = torch.zeros_like(q); dkv = torch.zeros_like(kv)
+        desc.set("O", o, 0, Tq * d, d); desc.set("dO", do, 0, Tq * d, d)
+        desc.set("dQ", dq, 0, Tq * d, d); desc.set("dK", dkv, 0, Tk * 2 * d, 2 * d); desc.set("dV", dkv, d, Tk * 2 * d, 2 * d)
+        ops.attention_fwd(desc, lse, ops.BF16)
+        ops.attention_bwd(desc, lse, delta, ops.BF16)
+        torch.cuda.synchronize()
+        out[v3] = (o, lse, delta, dq, dkv)
+    os.environ.pop("SMX_ATTN_V3", None)
+    for name, a, b in zip(("o", "lse", "delta", "dq", "dkv"), out["0"], out["1"]):
+        assert torch.equal(a, b), (name, B, H, Tq, Tk, causal, drop, klen, bias, (a.float() - b.float()).abs().max().item())
+    assert out["1"][0].float().abs().sum().item() > 0
+
+
+def test_resident_operand_attention_is_bit_identical_to_the_tile_staged_kernels():
+    """attention_v3.h (a head's K / V - or Q / dO - resident in LDS, no per-tile barrier) against attention_v2.h: same tile bodies in the same
+    order -> identical O, log-sum-exp, delta, dQ, dK, dV; self-attention at the encoders' lengths (499, 249), ragged lengths, cross shapes,
+    causal, dropout (bit masks), per-clip key lengths and the T5 bias."""
+    cases = [
+        (2, 3, 499, 499, False, None, None, False), (2, 3, 499, 499, False, (0.1, 77), None, False), (3, 2, 249, 249, False, (0.1, 5), None, False),
+        (2, 2, 131, 131, False, None, None, False), (2, 2, 512, 512, True, None, None, False), (2, 2, 300, 300, True, (0.2, 9), None, False),
+        (2, 2, 499, 499, False, None, [499, 313], False), (2, 2, 249, 249, False, (0.1, 3), [100, 249], False),
+        (2, 2, 200, 384, False, None, None, False), (1, 2, 257, 129, False, (0.1, 11), None, False), (2, 2, 256, 256, False, None, None, True),
+        (1, 2, 130, 130, True, (0.1, 4), None, True),
+    ]
+    for i, c in enumerate(cases):
+        _attn_case(*c, seed=100 + i)
