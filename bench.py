@@ -230,7 +230,10 @@ def main():
         dist.init_process_group("gloo")
         t = torch.tensor([float(rank)])
         dist.all_reduce(t)
-        print(json.dumps({"spawn_check": True, "rank": rank, "world": world, "gpus": args.gpus, "rank_sum": t.item()}), flush=True)
+        # (ONE write per rank: with an unbuffered stdout `print` sends the text and the newline separately, and two ranks' lines on one
+        #  pipe then interleave - the flaky parse of round 5)
+        sys.stdout.write(json.dumps({"spawn_check": True, "rank": rank, "world": world, "gpus": args.gpus, "rank_sum": t.item()}) + "\n")
+        sys.stdout.flush()
         dist.destroy_process_group()
         return
     # SMX_BENCH_SHARED_GPU=1 (tests/test_gpu_r3.py): every rank on cuda:0 over gloo - the N > 1 logic (stage buckets on the side

@@ -257,6 +257,31 @@ int smx_allreduce_bucket(void* comm, void* buf, size_t n, int dtype, hipStream_t
 double smx_probe_mfma(float* out, int blocks, int iters, hipStream_t stream);
 int smx_probe_copy(const void* src, void* dst, long long bytes, hipStream_t stream);
 
+/* Batched 2-D transposes of 16-bit matrices (round 6): dst[cols][rows] = src[rows][cols] for up to SMX_TR_MAX matrices per launch
+ * (rows, cols multiples of 8, 16-byte aligned bases); tile0 / tcols are filled by the library.  Used for the K-contiguous copies of
+ * the Linear weights the data gradients may read (speechmix_amd/engine.py Engine._wt; weights of ref:speechmix/model.py:148's encoder,
+ * TF:models/wav2vec2/modeling_wav2vec2.py:466-572). */
+#define SMX_TR_MAX 64
+typedef struct SmxTrEntry { const void* src; void* dst; int rows, cols; int tile0, tcols; } SmxTrEntry;
+typedef struct SmxTrTable { int n, tiles; SmxTrEntry e[SMX_TR_MAX]; } SmxTrTable;
+int smx_transpose_many(const SmxTrTable* t, hipStream_t stream);
+int smx_sizeof_SmxTrTable(void);
+int smx_tr_max(void);
+
+/* x[i] = T(float(x[i]) * *scale) in place, `scale` one fp32 word in device memory: the seed of backward scaled by the device scalar
+ * autograd hands to loss.backward() (1 / k under the reference's gradient accumulation, ref:train.py:291-330) without a host read. */
+int smx_scale_dev(void* x, long long n, const float* scale, int dtype, hipStream_t stream);
+
+/* Per-step dropout key (round 5): every translation unit whose kernels hash dropout masks keeps one device word that
+ * smx_set_step_key rewrites on the stream; these return the word's device address (diagnostics; smx_set_step_key collects them). */
+int smx_step_key_addr_misc(void** out);
+int smx_step_key_addr_gemm(void** out);
+int smx_step_key_addr_gemm_pp(void** out);
+int smx_step_key_addr_gemm_fr(void** out);
+int smx_step_key_addr_gemm_ws(void** out);
+int smx_step_key_addr_norm(void** out);
+int smx_step_key_addr_attention(void** out);
+
 /* ABI self-description */
 int smx_sizeof_SmxGemmParams(void);
 int smx_sizeof_SmxNormParams(void);

@@ -436,6 +436,32 @@ extern "C" int smx_transpose_many(const SmxTrTable* tp, hipStream_t stream) {
     hipLaunchKernelGGL(transpose_many_kernel, dim3(tiles), dim3(256), 0, stream, t);
     SMX_CHECK_LAUNCH();
 }
+// x[i] = T(float(x[i]) * *scale) in place: the seed of backward scaled by the DEVICE scalar autograd hands to `loss.backward()`
+// (1 / k under gradient accumulation) in fp32 - one rounding per element, no host read of the scalar (model.py _StepFn.backward)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_dev_kernel(T* __restrict__ x, long long n, const float* __restrict__ scale) {
+    const float s = *scale;
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 + 8 <= n) {
+        float v[8];
+        load8(x + i0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= s;
+        store8(x + i0, v);
+    } else {
+        for (long long i = i0; i < n; ++i) Cvt<T>::st(x + i, Cvt<T>::ld(x + i) * s);
+    }
+}
+extern "C" int smx_scale_dev(void* x, long long n, const float* scale, int dtype, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (!x || !scale || n < 0 || ((size_t)x & 15)) return SMX_EINVAL;
+    if (n == 0) return SMX_OK;
+    const unsigned grid = (unsigned)((n + 2047) / 2048);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(scale_dev_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (bf16_t*)x, n, scale);
+    else if (dtype == SMX_F32) hipLaunchKernelGGL(scale_dev_kernel<float>, dim3(grid), dim3(256), 0, stream, (float*)x, n, scale);
+    else return SMX_EINVAL;
+    SMX_CHECK_LAUNCH();
+}
 extern "C" int smx_sizeof_SmxTrTable(void) { return (int)sizeof(SmxTrTable); }
 extern "C" int smx_tr_max(void) { return SMX_TR_MAX; }
 

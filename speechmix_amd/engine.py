@@ -148,6 +148,9 @@ class Engine:
         self.ep, self.lp = enc_prefix, lm_prefix
         self._persist: Dict[str, torch.Tensor] = {}
         self.last_dropped: List[int] = []
+        # encoder layers that LayerDrop skipped in EVERY backward since the gradients were last zeroed (gradient accumulation: a layer kept in
+        # one micro-batch holds a gradient; FusedAdafactor / StepRunner skip only these - what HF's `grad is None` amounts to)
+        self.dropped_since_zero: set = set()
         self.saved = None
         rank = int(os.environ.get("RANK", "0"))
         # SpecAugment spans and LayerDrop decisions: HF's own host streams in HF's draw order (injectable: tests, replays)
@@ -2445,6 +2448,27 @@ class Engine:
             if self.folds is not None:
                 self.folds.items.clear()
 
+    def note_dropped(self, zeroed):
+        """Called after every backward (eager or replayed) with `last_dropped` of its forward."""
+        cur = set(self.last_dropped)
+        self.dropped_since_zero = cur if zeroed else (self.dropped_since_zero & cur)
+
+    def reset_side_state(self):
+        """Drop whatever a backward that did not finish (an aborted capture pass) left queued: deferred weight gradients / column sums,
+        the second-stream flags, pending events and the folds - nothing of it may reach the next eager step."""
+        self._side_active = False
+        ops.GEMM_CONCURRENT = False
+        for name in ("_wg_defer", "_wg_group", "_wg_rows", "_cs_defer"):
+            v = getattr(self, name, None)
+            if isinstance(v, (list, dict)):
+                v.clear()
+        for name in ("_cs_pending", "_head_ev"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        if self.folds is not None:
+            self.folds.items.clear()
+        self.saved = None
+
     def lm_side_bwd(self, dlogits, lsv, gscale, extra_denc=None):
         """LM backward with the LM stage's weight gradients on the second compute stream (joined by the next _stage)."""
         if os.environ.get("SMX_LM_WGRAD_STREAM") != "0" and self.st.device.type == "cuda":
@@ -2465,4 +2489,5 @@ class Engine:
         de = self.lm_side_bwd(sv["dlogits"], sv["lm"], gscale, extra_denc=extra)
         self.speech_side_bwd(de, sv)
         self.end_grads()
+        self.note_dropped(zero_grads)
         self.saved = None

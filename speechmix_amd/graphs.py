@@ -163,11 +163,14 @@ class StepGraphs:
                 except Exception:
                     pass
                 self.graphs.clear()
+                eng.reset_side_state()          # (a backward that stopped half-way: nothing it queued may reach the next eager step)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.out = dict(loss=out["loss"], argmax=out["argmax"], T=out["T"])
         self.L = eng.L
         self.training = bool(fwd_kwargs.get("training"))
+        lmt = fwd_kwargs.get("lm_training")
+        self.keyed_pass = self.training or bool(lmt)          # Engine.forward: begin_pass(training or lm_training)
         return self
 
     # ---- replay
@@ -212,13 +215,16 @@ class StepGraphs:
                     pm = eng._premask
                 if pm is None:
                     raise RuntimeError("graph replay: attention dropout masks could not be generated")
-            eng.begin_pass(True)                         # the step key (set on the stream ahead of the first graph)
-            if self.uses_premask and pm.get("ev") is not None:
-                torch.cuda.current_stream().wait_event(pm["ev"])
-                pm["ev"] = None
         else:
             for i in range(self.L):
                 eng.host_rng.layerdrop()                 # HF draws in eval mode too (Engine.speech_fwd)
+        if self.keyed_pass:
+            # the step key (set on the stream ahead of the first graph) - also with the speech encoder in eval mode and the LM in train
+            # mode: the captured LM dropout sites hash with the key, and a replay that never refreshed it drew the same masks every step
+            eng.begin_pass(True)
+        if self.training and self.uses_premask and pm.get("ev") is not None:
+            torch.cuda.current_stream().wait_event(pm["ev"])
+            pm["ev"] = None
         cb = eng.stage_cb
         sr = getattr(eng, "stage_ranges", None) or {}
         c = self.carry
@@ -251,5 +257,6 @@ class StepGraphs:
             if cb is not None and name.startswith("stage:"):
                 cb(name[6:])
         eng.last_dropped = [i for i in range(self.L) if not kept[i]]
+        eng.note_dropped(True)                           # (a replayed backward zeroes the gradients first, as its capture pass did)
         eng.saved = None
         return self.out

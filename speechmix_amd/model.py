@@ -122,9 +122,14 @@ class _StepFn(torch.autograd.Function):
         # multiplied by the scalar on the device instead; exact for the usual values (1, powers of two).
         sv = model.engine.saved
         if sv is not None and torch.is_tensor(sv.get("dlogits")) and gloss.is_cuda:
-            sv["dlogits"].mul_(gloss.to(sv["dlogits"].dtype))
+            # (the product is formed in fp32 from the fp32 scalar: a bf16 copy of 1 / 3 - the reference's default accumulation - is 0.2 % off)
+            g32 = gloss.detach().reshape(()).float().contiguous()
+            if sv["dlogits"].is_contiguous() and not (sv["dlogits"].data_ptr() & 15):
+                ops.scale_dev(sv["dlogits"], g32)
+            else:
+                sv["dlogits"] = (sv["dlogits"].float() * g32).to(sv["dlogits"].dtype)
             if sv.get("extra_denc") is not None:
-                sv["extra_denc"] = sv["extra_denc"] * gloss.to(sv["extra_denc"].dtype)
+                sv["extra_denc"] = (sv["extra_denc"].float() * g32).to(sv["extra_denc"].dtype)
             gscale = 1.0
         else:
             gscale = float(gloss)          # (streamed LM head: the scale is a launch parameter of the recomputed chunks)

@@ -1157,6 +1157,13 @@ def copy_bytes(src, dst, nbytes=None):
     L.check(L.lib().smx_copy_bytes(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_longlong(n), _stream()), "smx_copy_bytes")
 
 
+def scale_dev(x, scale):
+    """x *= scale in place, `scale` a 0-dim fp32 DEVICE tensor, the product formed in fp32 (one rounding per element, no host read)."""
+    dt = BF16 if x.dtype == torch.bfloat16 else F32
+    assert x.is_contiguous() and scale.dtype == torch.float32 and scale.is_cuda and x.dtype in (torch.bfloat16, torch.float32)
+    L.check(L.lib().smx_scale_dev(C.c_void_p(x.data_ptr()), C.c_longlong(x.numel()), C.c_void_p(scale.data_ptr()), dt, _stream()), "smx_scale_dev")
+
+
 def dropout(x, out, n, p, seed, dtype):
     """out = x * mask(seed) / (1 - p), mask index = flat element index (same function the fused epilogues use)."""
     L.check(L.lib().smx_dropout(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), C.c_longlong(n), C.c_float(p), C.c_uint(seed), dtype, _stream()), "smx_dropout")

@@ -58,7 +58,8 @@ class FusedAdafactor(torch.optim.Optimizer):
         # skipped for LayerDrop there, exactly as StepRunner does)
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        dropped = set() if multi else set(getattr(self.model.engine, "last_dropped", ()) or ())
+        # (dropped in EVERY micro-batch since zero_grad: under gradient accumulation a layer kept once holds a gradient - ADVICE r5)
+        dropped = set() if multi else set(getattr(self.model.engine, "dropped_since_zero", ()) or ())
         active = []
         for nm, l, p, gp in zip(self.names, self._layer, self._params, self._gptr):
             on = bool(p.requires_grad and p.grad is not None and l not in dropped)

@@ -132,6 +132,7 @@ class StepRunner:
         stage marks) and weighted-sum models in train mode stay eager."""
         from . import graphs
         eng, st = self.engine, self.store
+        self._trial_mode = None          # the mode this step's timing sample belongs to (set below only on the trial's own steps)
         if (not graphs.ENABLED or not self.use_graphs or st.device.type != "cuda" or self.grad_accum != 1
                 or ops.GEMM_PROFILE is not None or ops.OP_PROFILE is not None or getattr(eng, "marks", None) is not None
                 or (fwd_kw["weighted_sum"] and fwd_kw["training"]) or self._graph_failures >= 2):
@@ -149,10 +150,10 @@ class StepRunner:
             tr = self._graph_trial
             if tr is not None:                         # auto mode's trial: TRIAL_STEPS replayed, then TRIAL_STEPS eager, timed
                 if len(tr["replay"]) < graphs.TRIAL_STEPS:
-                    tr["now"] = "replay"
+                    self._trial_mode = "replay"
                     return G
                 if len(tr["eager"]) < graphs.TRIAL_STEPS:
-                    tr["now"] = "eager"
+                    self._trial_mode = "eager"
                     return None
                 self._graph_decide(key)
                 return self._graphs
@@ -164,7 +165,7 @@ class StepRunner:
             return None
         try:
             G = graphs.StepGraphs(self, key).capture(wave, dec_ids.contiguous(), labels.contiguous(), text, fwd_kw)
-        except RuntimeError as e:          # (ops.CaptureAbort included) stay eager; a second failure disables capturing
+        except Exception as e:             # (ops.CaptureAbort included) stay eager; a second failure disables capturing
             import warnings
             self._graph_failures += 1
             self._graph_warm = {}
@@ -172,8 +173,9 @@ class StepRunner:
             self.engine.saved = None
             return None
         self._graphs = G
-        if graphs.MODE == "auto":
-            self._graph_trial = dict(replay=[], eager=[], now="replay")
+        if graphs.MODE == "auto" and self._graph_choice.get(key) != "replay":          # (a configuration already measured is not trialled again)
+            self._graph_trial = dict(replay=[], eager=[])
+            self._trial_mode = "replay"
         return G
 
     def _graph_decide(self, key):
@@ -222,7 +224,7 @@ class StepRunner:
         training = m.training and m.encoder_model.training
         fwd_kw = dict(training=training, weighted_sum=m.weighted_sum, lm_training=m._lm_training(), want_logits=False)
         G = self._step_graphs(wave, decoder_input_ids, labels, text, fwd_kw)
-        trial = self._graph_trial
+        trial = self._graph_trial if getattr(self, "_trial_mode", None) else None          # (steps that are eager for another reason are not samples)
         if trial is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
@@ -240,7 +242,7 @@ class StepRunner:
                 eng.stage_cb = cb
         if trial is not None:
             ev[1].record()
-            trial[trial["now"]].append(ev)
+            trial[self._trial_mode].append(ev)
         # LayerDrop: a layer is without a gradient for this update only if every micro-batch dropped it
         self._dropped_all = set(eng.last_dropped) if first else (self._dropped_all & set(eng.last_dropped))
         if not last:

@@ -23,7 +23,18 @@ def lib():
 
 def _declared():
     src = open(HEADER).read()
-    return sorted(set(re.findall(r"^\s*int\s+(smx_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|double|long long|void|size_t)\s+(smx_\w+)\s*\(", src, flags=re.M)))
+
+
+def test_every_exported_symbol_is_declared(lib):
+    """The other direction: nothing the library exports under the smx_ prefix may be missing from the header."""
+    from speechmix_amd import _lib as L
+    path = L.lib()._name
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("smx_")})
+    assert len(exported) >= 80
+    missing = [n for n in exported if n not in set(_declared())]
+    assert not missing, f"exported but not declared in include/speechmix_hip.h: {missing}"
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -38,9 +49,11 @@ def test_struct_layouts_match_ctypes(lib):
     for name, st in (("SmxGemmParams", L.GemmParams), ("SmxNormParams", L.NormParams), ("SmxNormBwdParams", L.NormBwdParams),
                      ("SmxAttnParams", L.AttnParams), ("SmxConv0Params", L.Conv0Params), ("SmxCEParams", L.CEParams),
                      ("SmxOptParams", L.OptParams), ("SmxWsumParams", L.WsumParams), ("SmxAfParams", L.AfParams),
-                     ("SmxAfTensor", L.AfTensor), ("SmxAfTile", L.AfTile), ("SmxAfSeg", L.AfSeg), ("SmxFoldTable", L.FoldTable)):
+                     ("SmxAfTensor", L.AfTensor), ("SmxAfTile", L.AfTile), ("SmxAfSeg", L.AfSeg), ("SmxFoldTable", L.FoldTable),
+                     ("SmxTrTable", L.TrTable)):
         assert getattr(lib, "smx_sizeof_" + name)() == C.sizeof(st), name
     assert lib.smx_fold_max() == L.FOLD_MAX
+    assert lib.smx_tr_max() == L.TR_MAX
 
 
 def test_header_is_plain_c_and_agrees_with_library(lib, tmp_path):

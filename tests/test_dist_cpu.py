@@ -193,3 +193,87 @@ def test_allreduce_modes_and_shared_tuner_picks_gloo_world2():
         assert out["rs_ag_1"] == 0.0 and out["rs_ag_2"] == 0.0 and out["rs_ag_1002"] == 0.0
         assert 0.0 < out["bf16"] < 5e-2                       # bf16 rounding of the summed gradient, nothing worse
     assert res[0][2] == (8, None) and res[1][2] == (8, 13)
+
+
+# ------------------------------------------------------------------------------------------------ 8 ranks
+def _worker8(rank, world, port, q):
+    """GradReducer + reduce_bucket(mode="rs_ag") at the world size of BASELINE config 3 (TF:trainer.py:720-737's DDP over 8 ranks): bucket
+    sizes that do not divide by 8, a frozen LM, per-rank LayerDrop (a rank that dropped a layer contributes zeros for it and still takes
+    part in its collectives) and ranks that report different prefixes of the stage order before finish()."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import speechmix_amd.dist as D
+        D.ALLREDUCE_MODE = "rs_ag"
+        log = []
+        real_ar, real_ag = dist.all_reduce, dist.all_gather
+
+        def ar(t, *a, **k):
+            log.append(("all_reduce", t.numel()))
+            return real_ar(t, *a, **k)
+
+        def ag(lst, t, *a, **k):
+            log.append(("all_gather", t.numel(), len(lst)))
+            return real_ag(lst, t, *a, **k)
+        dist.all_reduce, dist.all_gather = ar, ag
+        L = 3
+        offsets, off = {}, 0
+        names = ["decoder_model.model.shared.weight", "decoder_model.model.decoder.layers.0.fc1.weight", "length_adapters.0.weight",
+                 "enc_to_dec_proj.weight"] + [f"encoder_model.encoder.layers.{i}.attention.q_proj.weight" for i in range(L)] + \
+                ["encoder_model.feature_extractor.conv_layers.0.conv.weight", "encoder_model.masked_spec_embed"]
+        for i, n in enumerate(names):
+            numel = 1003 + 37 * i                          # never a multiple of 8
+            offsets[n] = (off, numel, (numel,))
+            off = (off + numel + 63) // 64 * 64
+        total = off
+        frozen = lambda n: n.startswith("decoder_model.")                   # SpeechMixFixed-style: the LM is not reduced
+        gen = torch.Generator().manual_seed(100 + rank)
+        g = torch.randn(total, generator=gen)
+        dropped = rank % L                                                   # this rank's LayerDrop draw
+        o, k, _ = offsets[f"encoder_model.encoder.layers.{dropped}.attention.q_proj.weight"]
+        g[o:o + k] = 0.0
+        # the single-process answer: the sum of every rank's buffer
+        want = torch.zeros(total)
+        for r in range(world):
+            gr = torch.randn(total, generator=torch.Generator().manual_seed(100 + r))
+            oo, kk, _ = offsets[f"encoder_model.encoder.layers.{r % L}.attention.q_proj.weight"]
+            gr[oo:oo + kk] = 0.0
+            want += gr
+        mine = g.clone()
+        stages = D.stage_ranges(offsets, L, trainable=lambda n: not frozen(n))
+        red = D.GradReducer(g, stages)
+        red.begin_step()
+        order = [s for s, _ in stages]
+        for s in order[:1 + rank % 4]:                                       # a rank-dependent prefix; finish() takes the rest in order
+            red.stage_done(s)
+        red.finish()
+        ok = True
+        for n, (o, k, _) in offsets.items():
+            if frozen(n):
+                ok &= bool(torch.equal(g[o:o + k], mine[o:o + k]))          # untouched
+            else:
+                ok &= bool(torch.allclose(g[o:o + k], want[o:o + k], rtol=1e-5, atol=1e-5))
+        q.put((rank, ok, log))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rs_ag_buckets_gloo_world8_non_divisible_frozen_layerdrop():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert all(ok for _, ok, _ in res), [r for r, ok, _ in res if not ok]
+    logs = [lg for _, _, lg in res]
+    assert all(lg == logs[0] for lg in logs), "ranks issued different collective sequences"
+    kinds = {e[0] for e in logs[0]}
+    assert kinds == {"all_reduce", "all_gather"} and len(logs[0]) >= 10          # shard exchange + non-divisible remainders

@@ -137,3 +137,117 @@ def test_resident_operand_attention_is_bit_identical_to_the_tile_staged_kernels(
     ]
     for i, c in enumerate(cases):
         _attn_case(*c, seed=100 + i)
+
+
+def test_fused_adafactor_under_gradient_accumulation_with_layerdrop():
+    """with k accumulated micro-batches (the reference's train.py default is 3) a LayerDrop-dropped layer is without a gradient only
+    if EVERY micro-batch dropped it; FusedAdafactor used the last forward's draws and threw away the gradient of a layer kept in micro-batches
+    1 - 2 and dropped in 3.  Four updates of three micro-batches each at layerdrop 0.5, against transformers' Adafactor on a twin whose
+    all-dropped layers get `.grad = None` (what the HF model's autograd leaves), loss / 3 per micro-batch (a non-power-of-two device scalar:
+    the fp32 scaling of the backward seed, model.py)."""
+    transformers = pytest.importorskip("transformers")
+    import contextlib, io
+    from transformers.optimization import Adafactor
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.optim import FusedAdafactor
+    from tests.test_gpu_r5b import ENC, LM
+
+    def build():
+        with contextlib.redirect_stdout(io.StringIO()):
+            return SpeechMixEED(dict(ENC, layerdrop=0.5), LM, down_scale=2, compute_dtype="fp32", init_seed=2).train()
+    a, b = build(), build()
+    hf = Adafactor([p for p in a.parameters() if p.requires_grad], lr=1e-2, scale_parameter=False, relative_step=False, warmup_init=False)
+    a.store.external_updates = True
+    fu = FusedAdafactor(b, lr=1e-2, max_grad_norm=0.0)
+    g = torch.Generator().manual_seed(0)
+    L = ENC["num_hidden_layers"]
+    pre = a.engine.ep + "encoder.layers."
+    late_drop = 0          # updates in which a layer was kept in an earlier micro-batch and dropped in the last one
+    for step in range(4):
+        sets = []
+        for micro in range(3):
+            wave = (torch.randn(3, 9000, generator=g) * 0.1).cuda()
+            labels = torch.randint(4, 120, (3, 6), generator=g).cuda()
+            losses = []
+            for m in (a, b):
+                torch.manual_seed(1000 + 10 * step + micro)          # the same LayerDrop draws for both models
+                import numpy as np
+                np.random.seed(1000 + 10 * step + micro)
+                loss = m(wave, labels=labels)["loss"]
+                (loss / 3).backward()
+                losses.append(loss.item())
+            assert a.engine.last_dropped == b.engine.last_dropped
+            assert abs(losses[0] - losses[1]) <= 2e-4 * max(1.0, abs(losses[0])), (step, micro, losses)
+            sets.append(set(a.engine.last_dropped))
+        all_dropped = sets[0] & sets[1] & sets[2]
+        late_drop += int(bool(sets[2] - all_dropped))
+        assert b.engine.dropped_since_zero == all_dropped, (b.engine.dropped_since_zero, sets)
+        for n, p in a.named_parameters():
+            if n.startswith(pre) and int(n[len(pre):].split(".", 1)[0]) in all_dropped:
+                p.grad = None
+        hf.step()
+        a.zero_grad(set_to_none=True)
+        fu.step()
+        b.zero_grad(set_to_none=True)
+    assert late_drop >= 1, "the seeds never produced the case under test"
+    torch.cuda.synchronize()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for n in pa:
+        if n.endswith("k_proj.bias"):
+            continue          # (zero gradient in exact arithmetic: tests/test_gpu_r5b.py)
+        x, y = pa[n].detach(), pb[n].detach()
+        scale = max(x.abs().max().item(), 1e-3)
+        assert (x - y).abs().max().item() <= 5e-4 * scale + 1e-7, (n, (x - y).abs().max().item(), scale)
+
+
+def test_scale_dev_multiplies_in_fp32():
+    from speechmix_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    x = torch.randn(1024 * 50265 // 64 + 5, device=dev).bfloat16()
+    s = torch.tensor(1.0 / 3.0, device=dev)
+    want = (x.float() * s).bfloat16()
+    y = x.clone()
+    ops.scale_dev(y, s)
+    assert torch.equal(y, want)
+    z = torch.randn(1003, device=dev)
+    w = z.clone()
+    ops.scale_dev(w, s)
+    assert torch.equal(w, z * s)
+
+
+def test_graph_replay_with_the_speech_encoder_in_eval_mode_and_the_lm_in_train_mode():
+    """`model.train(); model.encoder_model.eval()` - a frozen-encoder set-up - replays the captured step with the LM's dropout sites
+    live; the replay must refresh the step key (it did so only when the ENCODER was in train mode, so every replayed step drew the masks of
+    whatever key was set last).  Eager vs replayed: bit-identical gradients of the weight matrices step by step, and successive replayed
+    steps differ."""
+    import contextlib, io
+    from speechmix_amd import graphs
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.trainer import StepRunner
+    from tests.test_gpu_r5 import ENC, LM, _compare
+
+    def run(use_graphs, steps=9):
+        graphs.MODE, graphs.ENABLED = "1", True
+        g = torch.Generator().manual_seed(0)
+        wave = (torch.randn(4, 12000, generator=g) * 0.1).cuda()
+        labels = torch.randint(4, 200, (4, 6), generator=g).cuda()
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = SpeechMixEED(ENC, LM, down_scale=2, compute_dtype="bf16", init_seed=0)
+        m.train()
+        m.encoder_model.eval()
+        r = StepRunner(m, lr=0.0, optimizer="sgd", max_grad_norm=0.0, seed=5)
+        r.use_graphs = use_graphs
+        out = []
+        for s in range(steps):
+            loss = r.step(wave, labels)
+            torch.cuda.synchronize()
+            out.append(dict(grad=m.store.grad.clone(), dropped=list(m.engine.last_dropped), loss=float(loss.item()),
+                            master=m.store.master.clone(), graphed=r._graphs is not None))
+        return out, {n: (o, k, s) for n, (o, k, s) in m.store.offsets.items()}
+    eager, offs = run(False)
+    graph, _ = run(True)
+    assert not any(s["graphed"] for s in eager) and graph[-1]["graphed"] and graph[-2]["graphed"]
+    _compare(eager, graph, offs)
+    assert not torch.equal(graph[-1]["grad"], graph[-2]["grad"])          # fresh LM dropout masks every replayed step
+    assert not torch.equal(eager[-1]["grad"], eager[-2]["grad"])

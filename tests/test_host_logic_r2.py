@@ -175,7 +175,9 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    import re
+    # every rank's object, wherever it landed on the shared pipe (the objects hold no nested braces)
+    lines = [json.loads(m) for m in re.findall(r'\{"spawn_check"[^{}]*\}', r.stdout)]
     assert sorted(l["rank"] for l in lines) == [0, 1]
     assert all(l["world"] == 2 and l["gpus"] == 2 and l["rank_sum"] == 1.0 for l in lines)
 
