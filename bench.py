@@ -169,6 +169,28 @@ def measured_peaks(device):
         e1.record()
         torch.cuda.synchronize()
         best = max(best, fl / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    # the same loop on zero and on non-zero operands with the shader clock each ran at (the guide's 2 495 TF/s is a
+    # zero-operand / high-clock figure; under real operands the chip holds a lower clock - MI355X_MICROARCH.md "DVFS give-back")
+    clocks = {}
+    try:
+        lib.smx_probe_mfma_clk.restype = C.c_double
+        clk = torch.zeros(2, dtype=torch.int64, device=device)
+        for name, zero in (("nonzero_operands", 0), ("zero_operands", 1)):
+            bt, ghz = 0.0, 0.0
+            for _ in range(3):
+                lib.smx_probe_mfma_clk(C.c_void_p(outb.data_ptr()), 512, 200, zero, C.c_void_p(clk.data_ptr()), st)
+                e0.record()
+                fl = lib.smx_probe_mfma_clk(C.c_void_p(outb.data_ptr()), 512, 2000, zero, C.c_void_p(clk.data_ptr()), st)
+                e1.record()
+                torch.cuda.synchronize()
+                tf = fl / (e0.elapsed_time(e1) * 1e-3) / 1e12
+                if tf > bt:
+                    c = clk.tolist()
+                    bt, ghz = tf, (c[0] / (10.0 * c[1]) if c[1] else 0.0)
+            clocks[name] = {"tflops": round(bt, 1), "shader_clock_GHz": round(ghz, 3),
+                            "tflops_at_2p4GHz": round(bt * 2.4 / ghz, 1) if ghz else None}
+    except Exception as e:
+        clocks = {"error": str(e)[:160]}
     n = 1 << 30
     src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
     dst = torch.empty_like(src)
@@ -182,6 +204,7 @@ def measured_peaks(device):
         torch.cuda.synchronize()
         bw = max(bw, 4 * 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     return {"mfma_bf16_tflops": round(best, 1), "mfma_probe": "v_mfma_f32_32x32x16_bf16 loop, 8 waves/CU, non-zero operands",
+            "mfma_by_operands": clocks,
             "hbm_copy_GBps": round(bw, 1), "hbm_probe": "1 GiB 16-B/lane copy, read + write bytes",
             "datasheet": {"mfma_bf16_tflops": MFMA_BF16_PEAK_TFLOPS, "hbm_GBps": HBM_PEAK_GBPS}}
 
@@ -213,6 +236,7 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="dropout / LayerDrop / SpecAugment off")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the extra p=0 pass reported beside the train-mode number")
     ap.add_argument("--no-trainer-leg", action="store_true", help="skip the Trainer-style loop (model(...).backward() + optimizer) legs")
+    ap.add_argument("--no-fresh-leg", action="store_true", help="skip the leg that feeds every step a new pinned host batch through DevicePrefetcher")
     ap.add_argument("--seed", type=int, default=None, help="seed the host streams (np.random: SpecAugment, torch: LayerDrop) for A/B runs")
     args = ap.parse_args()
 
@@ -363,6 +387,31 @@ def main():
         eval_ms = 1e3 * e2 / args.steps
         model.train()
 
+    # Fresh batches: the reference's step starts with `_prepare_inputs` - the collated [B, 160000] fp32 batch goes host ->
+    # device (ref:train.py:100-133 builds it).  The same K steps with every batch coming from PINNED host memory through
+    # speechmix_amd.data.DevicePrefetcher (copy on a side stream beside the previous step); reported beside the headline.
+    fresh = None
+    if world == 1 and not args.no_fresh_leg:
+        try:
+            from speechmix_amd.data import DevicePrefetcher
+            hb = []
+            for i in range(4):
+                w_, l_ = synth_batch(B, model.decoder_model.config.vocab_size, rank + 100 + i, torch.device("cpu"))
+                hb.append({"input_values": w_.pin_memory(), "labels": l_.pin_memory()})
+            nb = args.warmup + args.steps
+            tf0 = None
+            for i, b_ in enumerate(DevicePrefetcher((hb[j % 4] for j in range(nb)), device)):
+                if i == args.warmup:
+                    torch.cuda.synchronize()
+                    tf0 = time.perf_counter()
+                runner.step(b_["input_values"], b_["labels"])
+            torch.cuda.synchronize()
+            fms = 1e3 * (time.perf_counter() - tf0) / args.steps
+            fresh = {"ms_per_step": round(fms, 3), "value": round(B * CLIP_SECONDS / (fms * 1e-3), 1), "h2d_bytes_per_step": int(hb[0]["input_values"].numel() * 4 + hb[0]["labels"].numel() * 8),
+                     "what": "every step on a new batch: pinned host memory -> DevicePrefetcher (side-stream copy beside the previous step) -> StepRunner.step"}
+        except Exception as e:
+            fresh = {"error": str(e)[:300]}
+
     # The drop-in path itself: what ref:train.py:291-330 runs through HF Trainer per step - `model(**batch)["loss"]`,
     # `.backward()` (ONE autograd node over the engine), `clip_grad_norm_` over the parameters' `.grad` views of the flat buffer, the
     # optimizer, `zero_grad` - on the same batch: once with HF's own Adafactor (Trainer's optim="adafactor": a Python loop over ~460
@@ -432,6 +481,8 @@ def main():
             line["params_in_sync"] = in_sync
         if trainer_path is not None:
             line["trainer_path"] = trainer_path
+        if fresh is not None:
+            line["fresh_batch"] = fresh
         if world > 1:
             # why it scales the way it does: how long the gradient collectives ran beside backward and how much of that was
             # NOT hidden (compute stream waiting in GradReducer.finish), from the instrumented pass
@@ -478,7 +529,7 @@ def main():
                                      for k, v in fams.items()}
             # HBM-side bytes per launch of that family from the committed PMC passes of the same command (tools/pmc_traffic.py);
             # counters cannot be collected inside this process - `traffic_source` names the file
-            pmc = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json"))
+            pmc = next((f for f in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json"))
                         if os.path.exists(f)), "")
             if pmc:
                 stems = {"gemm_bf16_pp_kernel": ("gemm_bf16_pp_kernel", "gemm_bf16_pp_group_kernel")}.get(dom, (dom,))
@@ -486,7 +537,9 @@ def main():
                 nl = sum(v["launches"] for v in hits)
                 if nl:
                     line["roofline"]["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / nl)
-                    line["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    line["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(pmc)}: a COMMITTED profile (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                          "passes of this command on the builder's box, FETCH_SIZE doubled as the guide prescribes), not measured in "
+                                                          "this run - counters cannot be collected inside the process; " + json.load(open(pmc)).get("tree", "tree not recorded"))
             # The path's other kernel families against THEIR roofline: HBM-bound ones as algorithmic
             # bytes / measured time vs the 8 TB/s peak, attention as flops vs the MFMA peak
             osum = oprof.summary()

@@ -255,6 +255,9 @@ int smx_allreduce_bucket(void* comm, void* buf, size_t n, int dtype, hipStream_t
  * what this box delivers): a pure v_mfma_f32_32x32x16_bf16 loop (returns the flops one launch issues; time it with events)
  * and a 16-B-per-lane streaming copy (read + write). */
 double smx_probe_mfma(float* out, int blocks, int iters, hipStream_t stream);
+/* the same loop on zero (zero = 1) or non-zero operands, with block 0's shader cycles / 100-MHz ticks over the loop in clk[0] / clk[1]
+ * (device memory, may be null): the clock the chip sustains under the load is clk[0] / (10 clk[1]) GHz */
+double smx_probe_mfma_clk(float* out, int blocks, int iters, int zero, unsigned long long* clk, hipStream_t stream);
 int smx_probe_copy(const void* src, void* dst, long long bytes, hipStream_t stream);
 
 /* Batched 2-D transposes of 16-bit matrices (round 6): dst[cols][rows] = src[rows][cols] for up to SMX_TR_MAX matrices per launch

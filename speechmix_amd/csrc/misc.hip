@@ -953,6 +953,9 @@ __global__ __launch_bounds__(256) void wsum_dots_kernel(SmxWsumParams p) {
         if (threadIdx.x == 0) atomicAdd(p.dots + l, s);
     }
 }
+__global__ void wsum_zero_kernel(float* dots, int n) {
+    if ((int)threadIdx.x < n) dots[threadIdx.x] = 0.f;
+}
 __global__ void wsum_dw_kernel(SmxWsumParams p) {   // softmax backward on L+1 values
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float dot = 0.f;
@@ -975,7 +978,10 @@ extern "C" int smx_weighted_sum_bwd(const SmxWsumParams* pp, int dtype, hipStrea
     (void)hipGetLastError();
     SmxWsumParams p = *pp;
     if (p.L1 < 1 || p.L1 > WS_MAXL || (p.n & 7) || !p.dots || !p.dw || !p.sw) return SMX_EINVAL;
-    (void)hipMemsetAsync(p.dots, 0, sizeof(float) * p.L1, stream);
+    // (zeroed by a KERNEL: inside a stream capture hipMemsetAsync becomes a memset node, and the replayed node did not clear the 20-byte scratch
+    //  - dots[0] kept whatever the pool block held, which is what "one replayed hidden state holds garbage" of round 5 was: the weighted-sum
+    //  model is the only captured path that reached a memset; tests/test_gpu_r5.py with SMX_CAPTURE_GC_GUARD=collect failed 5 of 5 before, 0 after)
+    hipLaunchKernelGGL(wsum_zero_kernel, dim3(1), dim3(64), 0, stream, p.dots, p.L1);
     long long blocks = (p.n / 8 + 255) / 256;
     if (blocks > 512) blocks = 512;
     if (dtype == SMX_BF16) hipLaunchKernelGGL(wsum_dots_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, p);
@@ -1150,6 +1156,42 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(float* out, int iters) 
 #pragma unroll
     for (int e = 0; e < 16; ++e) s += a0[e] + a1[e] + a2[e] + a3[e];
     if (s == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;       // keeps the chains live, never true in practice
+}
+// The same loop with a choice of operands and the shader clock it ran at (the box's probe reads ~1 985 TF/s where the
+// guide measured 2 495): zero = 1 multiplies zeros - the chip then clocks ~20 % higher (DVFS, MI355X_MICROARCH.md); clk[0] / clk[1]
+// receive block 0's shader cycles (s_memtime) and its 100-MHz real-time ticks over the loop, i.e. GHz = clk[0] / (10 clk[1]).
+__global__ __launch_bounds__(256) void probe_mfma_clk_kernel(float* out, int iters, int zero, unsigned long long* clk) {
+    const int lane = threadIdx.x & 63;
+    bf16x8_t x, y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        x[e] = zero ? (short)0 : (short)(0x3f80 + ((lane * 37 + e * 11) & 0x7f) - ((lane + e) & 1) * 0x8000);
+        y[e] = zero ? (short)0 : (short)(0x3f00 + ((lane * 13 + e * 29) & 0x7f) - ((lane * 3 + e) & 1) * 0x8000);
+    }
+    probe_f32x16_t a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += a0[e] + a1[e] + a2[e] + a3[e];
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clk) { clk[0] = c1 - c0; clk[1] = r1 - r0; }
+    if (s == 1234.5678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+extern "C" double smx_probe_mfma_clk(float* out, int blocks, int iters, int zero, unsigned long long* clk, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (blocks <= 0 || iters <= 0 || !out) return -1.0;
+    hipLaunchKernelGGL(probe_mfma_clk_kernel, dim3(blocks), dim3(256), 0, stream, out, iters, zero, clk);
+    if (hipGetLastError() != hipSuccess) return -1.0;
+    return (double)blocks * 4.0 * (double)iters * 16.0 * 2.0 * 32.0 * 32.0 * 16.0;
 }
 // -> flops issued by one launch (the caller times it with events): blocks x 4 waves x iters x 16 MFMAs x 2 * 32 * 32 * 16
 extern "C" double smx_probe_mfma(float* out, int blocks, int iters, hipStream_t stream) {

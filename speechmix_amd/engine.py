@@ -37,7 +37,9 @@ def _act_id(name):
     return _ACT[name]
 
 
-WT_MODE = os.environ.get("SMX_DGRAD_WT", "1") != "0"      # data gradients read K-contiguous weight copies (Engine._wt)
+# Data gradients through K-contiguous weight copies (Engine._wt): OFF by default - the GEMMs get 0.3 ms per step faster and the step does not
+# (profiles/r06_probes_not_kept.txt: 31.57 vs 32.14 ms, three same-box runs each); SMX_DGRAD_WT=1 turns it on.
+WT_MODE = os.environ.get("SMX_DGRAD_WT", "0") == "1"
 WT_MIN_M = int(os.environ.get("SMX_DGRAD_WT_MINM", "4096"))
 
 class HFHostRNG:

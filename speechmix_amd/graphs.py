@@ -129,14 +129,17 @@ class StepGraphs:
         # No garbage collection while the capture is open: the capture pass runs a few thousand lines of ordinary Python, the cyclic collector
         # may fire anywhere in it, and whatever it finalises then - an older StepGraphs with its graphs and pool, a stream, an event - makes a
         # HIP call that is illegal on a capturing thread; the error is raised inside a destructor and the process aborts (seen once in the
-        # GPU suite, "Fatal Python error: Aborted / Garbage-collecting" under _gemm_params).  The collector is HELD, not run first:
-        # SMX_CAPTURE_GC_GUARD=collect (gc.collect() right before the capture, what torch.cuda.graph does) reproducibly corrupts one replayed
-        # hidden state of tests/test_gpu_r5.py's weighted-sum case when the models of its first half are finalised at that point - an open
-        # item; held-only and unguarded runs of the same test: 0 of 8 failures each.  0: no guard.
+        # GPU suite, "Fatal Python error: Aborted / Garbage-collecting" under _gemm_params).  So the collector runs right BEFORE the capture
+        # (what torch.cuda.graph does) and is held while it is open.  SMX_CAPTURE_GC_GUARD=hold: held only; 0: no guard.
+        # (Round 5 held it without collecting because collecting "corrupted one replayed hidden state" of the weighted-sum model.  Round 6
+        # found the cause, and it was not the collector: smx_weighted_sum_bwd cleared its 20-byte scratch with hipMemsetAsync, the capture
+        # turned that into a memset node, and the replayed node did not clear it - the first weight's dot product started from whatever the
+        # pool block held, which depended on what had been freed before the capture.  The scratch is zeroed by a kernel now: 6 of 6 runs
+        # of the test pass with the collect guard, 5 of 5 failed before.)
         gc_was = gc.isenabled()
-        gg = os.environ.get("SMX_CAPTURE_GC_GUARD", "1")
+        gg = os.environ.get("SMX_CAPTURE_GC_GUARD", "collect")
         if gg != "0":
-            if gg == "collect":
+            if gg != "hold":
                 gc.collect()
             gc.disable()
         try:
@@ -157,11 +160,28 @@ class StepGraphs:
             ops.CAPTURING = False
             eng.drop_rng.bit_generator.state = rng_state
             if not ok:
+                # A pass that stopped half-way (CaptureAbort behind a fork: a missing kernel pick in backward, a new transposed-weight entry)
+                # leaves the forked streams IN the capture: ending the capture then fails as "unjoined", the streams stay in capture mode, and
+                # the next HIP call that is illegal on a capturing thread - a CUDAGraph destructor - takes the process down (seen once with
+                # SMX_TUNE=live, round 6).  Join every stream that is capturing back into the origin first; the graph is discarded anyway.
+                for name in ("_side", "_wg_side", "_cs_stream", "_mask_stream"):
+                    st2 = getattr(eng, name, None)
+                    if st2 is None:
+                        continue
+                    try:
+                        with torch.cuda.stream(st2):
+                            forked = torch.cuda.is_current_stream_capturing()
+                        if forked:
+                            side.wait_stream(st2)
+                    except Exception:
+                        pass
                 try:
                     if self._cur is not None:
-                        self._cur.capture_end()
+                        with torch.cuda.stream(side):          # (the capture ends on the stream it began on - this handler runs outside the `with` above)
+                            self._cur.capture_end()
                 except Exception:
                     pass
+                self._cur = None                               # (the open graph goes first: its destructor ends a capture that is still open)
                 self.graphs.clear()
                 eng.reset_side_state()          # (a backward that stopped half-way: nothing it queued may reach the next eager step)
         torch.cuda.current_stream().wait_stream(side)

@@ -307,13 +307,6 @@ def test_graph_replay_of_speechmixself_with_a_t5_teacher_pass_and_of_a_weighted_
     assert [s["graphed"] for s in res[True][0]] == [False] * 3 + [True] * 6
     _compare(res[False][0], res[True][0], res[True][1])
     assert res[True][0][-1]["grad"].abs().max().item() > 0
-    # (the first half's models, runners and captured chains are finalised HERE, not at whatever moment the cyclic collector picks during the
-    # second half: finalising them right before the next capture is the open item of DESIGN.md 5a - SMX_CAPTURE_GC_GUARD=collect reproduces it)
-    if os.environ.get("SMX_CAPTURE_GC_GUARD") != "collect":
-        del res, model, r, steps
-        import gc
-        gc.collect()
-        torch.cuda.synchronize()
     # weighted sum, eval mode
     res = {}
     g = torch.Generator().manual_seed(0)

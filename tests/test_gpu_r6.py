@@ -251,3 +251,53 @@ def test_graph_replay_with_the_speech_encoder_in_eval_mode_and_the_lm_in_train_m
     _compare(eager, graph, offs)
     assert not torch.equal(graph[-1]["grad"], graph[-2]["grad"])          # fresh LM dropout masks every replayed step
     assert not torch.equal(eager[-1]["grad"], eager[-2]["grad"])
+
+
+def test_capture_abort_behind_a_fork_leaves_no_stream_capturing():
+    """A capture pass that stops in the middle of backward - after the weight-gradient streams were forked - must end the capture cleanly:
+    round 6 saw `~CUDAGraph: operation not permitted when stream is capturing` take a live-tuning bench process down (the forked streams
+    stayed in capture mode after the failed end of capture).  Here the 5th data gradient of the first capture pass raises CaptureAbort; the
+    runner falls back to eager, captures again a few steps later, replays, and everything can be destroyed."""
+    import contextlib, gc, io, warnings
+    from speechmix_amd import graphs, ops
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.trainer import StepRunner
+    from tests.test_gpu_r5 import ENC, LM
+    graphs.MODE, graphs.ENABLED = "1", True
+    g = torch.Generator().manual_seed(0)
+    wave = (torch.randn(4, 12000, generator=g) * 0.1).cuda()
+    labels = torch.randint(4, 200, (4, 6), generator=g).cuda()
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = SpeechMixEED(ENC, LM, down_scale=2, compute_dtype="bf16", init_seed=0).train()
+    r = StepRunner(m, lr=0.0, optimizer="sgd", max_grad_norm=0.0, seed=5)
+    r.use_graphs = True
+    eng = m.engine
+    state = {"calls": 0, "raised": 0}
+    orig = eng.dgrad
+
+    def dgrad(*a, **k):
+        if ops.CAPTURING and not state["raised"]:
+            state["calls"] += 1
+            if state["calls"] == 5:
+                state["raised"] = 1
+                raise ops.CaptureAbort("test: abort behind the fork")
+        return orig(*a, **k)
+    eng.dgrad = dgrad
+    graphed = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(12):
+            loss = r.step(wave, labels)
+            torch.cuda.synchronize()
+            assert torch.isfinite(loss).item(), step
+            graphed.append(r._graphs is not None)
+    assert state["raised"] == 1 and r._graph_failures == 1
+    assert graphed[-1] and not all(graphed), graphed          # the second attempt captured; the steps in between ran eagerly
+    for name in ("_side", "_wg_side", "_cs_stream", "_mask_stream"):
+        st = getattr(eng, name, None)
+        if st is not None:
+            with torch.cuda.stream(st):
+                assert not torch.cuda.is_current_stream_capturing(), name
+    del r, m, eng
+    gc.collect()
+    torch.cuda.synchronize()

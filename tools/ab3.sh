@@ -5,7 +5,7 @@ O=gpurun_out/ab3
 mkdir -p $O
 rm -f $O/*.jsonl $O/tune_*.json
 export TMPDIR=/tmp
-ARGS="--seed 1 --no-cpu-baseline --no-profile --no-eval-leg --no-trainer-leg --steps 40"
+ARGS="--seed 1 --no-cpu-baseline --no-profile --no-eval-leg --no-trainer-leg --no-fresh-leg --steps 40"
 i=0
 for cfg in "$@"; do
   env SMX_STEP_GRAPHS=0 SMX_TUNE_FILE=$PWD/$O/tune_$i.json $cfg timeout 400 python bench.py $ARGS --steps 5 > /dev/null 2>>$O/ab.err

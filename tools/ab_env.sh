@@ -5,7 +5,7 @@ VAR=$1; OFF=$2; ON=$3; PAIRS=${4:-3}
 O=gpurun_out/r5env_$VAR
 mkdir -p $O
 export TMPDIR=/tmp
-ARGS="--seed 1 --no-cpu-baseline --no-profile --no-eval-leg --no-trainer-leg --steps 40"
+ARGS="--seed 1 --no-cpu-baseline --no-profile --no-eval-leg --no-trainer-leg --no-fresh-leg --steps 40"
 for i in $(seq $PAIRS); do
   env SMX_STEP_GRAPHS=0 $VAR=$OFF timeout 300 python bench.py $ARGS 2>>$O/ab.err >> $O/ab_off.jsonl
   env SMX_STEP_GRAPHS=0 $VAR=$ON timeout 300 python bench.py $ARGS 2>>$O/ab.err >> $O/ab_on.jsonl
