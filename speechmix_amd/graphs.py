@@ -36,12 +36,12 @@ from . import ops
 # SMX_STEP_GRAPHS = auto (default) | 1 | 0.  What replay buys is HOST time (config 2: 18 ms of Python per step eager, 2.5 ms replayed);
 # on the GPU's clock the replayed step is the same kernels plus ~9 us of idle at each of its ~30 graph boundaries and at every
 # cross-queue dependency inside a graph (measured round 5: 32.05 vs 31.4 ms where the host keeps ahead of the GPU anyway).  So `auto`
-# MEASURES: after the capture, TRIAL_STEPS replayed and TRIAL_STEPS eager steps are timed with HIP events around forward + backward
-# and the faster mode is kept for that configuration (the captured buffers are released if eager wins).  `1` always replays.
+# MEASURES: after the capture, TRIAL_STEPS replayed and TRIAL_STEPS eager steps are timed with HIP events around the whole step
+# and the replayed schedule is kept if it wins by 2 % (else its captured buffers are released).  `1` always replays.
 MODE = os.environ.get("SMX_STEP_GRAPHS", "auto")
 ENABLED = MODE != "0"
 WARM_STEPS = int(os.environ.get("SMX_GRAPH_WARM_STEPS", "3"))      # eager steps of a configuration before its capture
-TRIAL_STEPS = int(os.environ.get("SMX_GRAPH_TRIAL_STEPS", "3"))
+TRIAL_STEPS = int(os.environ.get("SMX_GRAPH_TRIAL_STEPS", "5"))
 CAPTURE_MODE = os.environ.get("SMX_CAPTURE_MODE", "thread_local")          # hipStreamCaptureMode of the captures (see StepGraphs._begin)
 
 

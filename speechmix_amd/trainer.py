@@ -192,7 +192,9 @@ class StepRunner:
         # (every rank decides for itself, without a collective: a rank whose capture failed never gets here, and the two schedules
         # issue the same kernels and the same reductions in the same order - ranks in different modes stay bit-identical)
         self.graph_trial_ms = med
-        if med["eager"] <= med["replay"]:
+        # the replayed schedule has to WIN (2 %): on the GPU's clock the two tie within the noise of a few samples, and the eager schedule is
+        # the one every parity figure of the bench line was taken with
+        if med["eager"] * 0.98 <= med["replay"]:
             self._graph_choice[key] = "eager"
             self._graphs = None                        # (its static activations go back to the allocator)
         else:
@@ -240,9 +242,6 @@ class StepRunner:
                 eng.backward(gscale=1.0 / ga, zero_grads=first)
             finally:
                 eng.stage_cb = cb
-        if trial is not None:
-            ev[1].record()
-            trial[self._trial_mode].append(ev)
         # LayerDrop: a layer is without a gradient for this update only if every micro-batch dropped it
         self._dropped_all = set(eng.last_dropped) if first else (self._dropped_all & set(eng.last_dropped))
         if not last:
@@ -266,6 +265,9 @@ class StepRunner:
             self.af.step(st.master, st.grad, sh, lr, active=active,
                          grad_scale=inv_world, max_grad_norm=clip)
             st.mark_shadow_fresh()
+            if trial is not None:          # (the WHOLE step: forward + backward alone favoured the replay by up to 1.8 ms on steps that then tied)
+                ev[1].record()
+                trial[self._trial_mode].append(ev)
             return out["loss"]
         ranges = self.ranges if not dropped else trainable_ranges(st, dropped, self.layer_of)
         for a, b in ranges:
@@ -275,4 +277,7 @@ class StepRunner:
                                beta1=self.betas[0] if self.kind == "adamw" else self.momentum, beta2=self.betas[1],
                                eps=self.eps, weight_decay=self.wd, step=self.t, grad_scale=inv_world, max_grad_norm=clip)
         st.mark_shadow_fresh()
+        if trial is not None:
+            ev[1].record()
+            trial[self._trial_mode].append(ev)
         return out["loss"]

@@ -330,15 +330,18 @@ def test_graph_replay_of_speechmixself_with_a_t5_teacher_pass_and_of_a_weighted_
 
 
 def test_auto_mode_times_both_and_keeps_one():
-    """SMX_STEP_GRAPHS=auto (the default): 3 eager steps, the capture, 3 replayed + 3 eager timed steps, then ONE mode for good;
-    whatever it picks, every step equals the eager run."""
-    eager, offs, _ = _run_steps(False, 14)
-    auto, _, r = _run_steps(True, 14, mode="auto")
-    assert [s["graphed"] for s in auto][:9] == [False] * 3 + [True] * 6          # (captured chain alive through the trial)
+    """SMX_STEP_GRAPHS=auto (the default): 3 eager steps, the capture, T replayed + T eager timed steps (T = graphs.TRIAL_STEPS, whole steps
+    between HIP events), then ONE mode for good - the replayed one only if it wins by 2 %; whatever it picks, every step equals the eager run."""
+    from speechmix_amd import graphs
+    T = graphs.TRIAL_STEPS
+    n = 3 + 2 * T + 5
+    eager, offs, _ = _run_steps(False, n)
+    auto, _, r = _run_steps(True, n, mode="auto")
+    assert [s["graphed"] for s in auto][:3 + 2 * T] == [False] * 3 + [True] * (2 * T)          # (captured chain alive through the trial)
     assert r.graph_trial_ms is not None and set(r.graph_trial_ms) == {"replay", "eager"}
     choice = list(r._graph_choice.values())
     assert choice in (["eager"], ["replay"])
-    assert all(s["graphed"] == (choice == ["replay"]) for s in auto[10:])
+    assert all(s["graphed"] == (choice == ["replay"]) for s in auto[3 + 2 * T + 1:])
     _compare(eager, auto, offs)
 
 
