@@ -124,13 +124,44 @@ __device__ __forceinline__ void a2_bits4(const uint2& w, int t, int g4, unsigned
 }
 __device__ __forceinline__ float a2_and(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
 
+// SMX_ATTN_TRACE (lab builds, tools/gpu_attn_trace.py): shader-clock stamps at the phase boundaries of the forward tile body, summed per wave
+// over its tiles and written by lane 0 of every wave of workgroups 0..63: [wg][wave][phase] cycles + tile count
+#ifndef SMX_ATTN_TRACE
+#define SMX_ATTN_TRACE 0
+#endif
+#if SMX_ATTN_TRACE
+__device__ unsigned long long smx_attn_trace_buf[64 * 16 * 8];
+extern "C" int smx_attn_trace_read(void* host, unsigned long long bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(smx_attn_trace_buf), bytes) == hipSuccess ? SMX_OK : -5;
+}
+struct A2Trace {
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    __device__ __forceinline__ void start() { t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t = __builtin_readcyclecounter(); ph[i] += t - t0; t0 = t; __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ void flush(int wave, int ntiles) {
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 64 && wave < 16) {
+            unsigned long long* d = smx_attn_trace_buf + (blockIdx.x * 16 + wave) * 8;
+            for (int i = 0; i < 7; ++i) d[i] = ph[i];
+            d[7] = (unsigned long long)ntiles;
+        }
+    }
+};
+#define A2_TR_START(tr) (tr).start()
+#define A2_TR_MARK(tr, i) (tr).mark(i)
+#else
+struct A2Trace { __device__ __forceinline__ void flush(int, int) {} };
+#define A2_TR_START(tr) do { } while (0)
+#define A2_TR_MARK(tr, i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------- forward
 template <bool MASKED, bool BIAS, bool CAUSAL, bool DROP>
 __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* tK, const char* tV, const bf16x8_t (&qf)[2],
                                             f32x4_t (&o)[4], float& m, float& l, int k0, int q, int h, int lane, float sl2,
-                                            int coff, const uint2& mw, int tk) {
+                                            int coff, const uint2& mw, int tk, A2Trace* tr = nullptr) {
     const int g = lane >> 4;
     f32x4_t s[4];
+    A2_TR_MARK(*tr, 6);
     // All fragment reads of the tile are ISSUED before their first consumer: read-then-wait per MFMA made one tile a chain of
     // ~24 LDS latencies (2 900 cycles per tile for a lone wave with the global traffic and the barrier compiled out).
     // K fragments first, the score MFMAs behind them; the V fragments right after, in flight under the softmax arithmetic.
@@ -143,10 +174,12 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kcur[1], qf[1], s[t], 0, 0, 0);
         kcur[0] = knxt[0]; kcur[1] = knxt[1];
     }
+    A2_TR_MARK(*tr, 0);
     bf16x8_t vfr0[4], vfr1[4];                 // V fragments of the first reduction step: in flight under the softmax arithmetic
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vfr0[dt] = frag_tr(tV, 0, 16, dt * 16, lane);
     __builtin_amdgcn_sched_barrier(0);
+    A2_TR_MARK(*tr, 1);
     float mul = sl2;
     if constexpr (BIAS) {                       // T5 relative-position bias: scores leave this block in log2 units
         mul = 1.f;
@@ -181,6 +214,10 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
     const float mn = a2_max(m, mx * mul);
     const float alpha = fast_exp2(m - mn);
     float rs = 0.f;
+#if SMX_ATTN_TRACE
+    asm volatile("" : "+v"(rs) : "v"(alpha));
+#endif
+    A2_TR_MARK(*tr, 2);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         unsigned bm[4];
@@ -194,11 +231,16 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
     }
     l = fmaf(l, alpha, rs);                      // per-lane partial: reduced across the lane groups after the last tile
     m = mn;
+#if SMX_ATTN_TRACE
+    asm volatile("" : "+v"(l));
+#endif
+    A2_TR_MARK(*tr, 3);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vfr1[dt] = frag_tr(tV, 32, 48, dt * 16, lane);       // second step's, under the first's MFMAs
     __builtin_amdgcn_sched_barrier(0);
+    A2_TR_MARK(*tr, 4);
     {                                            // two 32-key reduction steps
         const bf16x8_t pf0 = pack_pair(s[0], s[1]);
 #pragma unroll
@@ -207,6 +249,7 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr1[dt], pf1, o[dt], 0, 0, 0);
     }
+    A2_TR_MARK(*tr, 5);
 }
 
 template <bool BIAS, bool CAUSAL, bool DROP>
@@ -244,6 +287,9 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttn
     tile_store(sV[0], rv, tid);
     __syncthreads();
     int buf = 0;
+    A2Trace trc;
+    int ntl = 0;
+    A2_TR_START(trc);
     const bool lab_noload = !DROP && p.drop_seed == 0xdead0001u;      // LAB: timing without the tile traffic (wrong results)
     const bool lab_nosync = !DROP && p.drop_seed == 0xdead0002u;      // LAB: ... and without the per-tile barrier
     for (int k0 = 0; k0 < kend; k0 += 64) {
@@ -256,8 +302,9 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttn
         }
         // masks only where they can bite: the ragged last key tile, and tiles crossing the causal diagonal
         const bool masked = (k0 + 64 > tk) || (CAUSAL && k0 + 63 > qb0 + coff);
-        if (masked) a2_fwd_tile<true, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk);
-        else a2_fwd_tile<false, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk);
+        if (masked) a2_fwd_tile<true, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk, &trc);
+        else a2_fwd_tile<false, BIAS, CAUSAL, DROP>(p, sK[buf], sV[buf], qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk, &trc);
+        ++ntl;
         if (more) {
             tile_store(sK[buf ^ 1], rk, tid);
             tile_store(sV[buf ^ 1], rv, tid);
@@ -265,6 +312,7 @@ __global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttn
         if (!lab_nosync) __syncthreads();       // next tile published; everyone is done with this one before it is overwritten next round
         if (!lab_noload && !lab_nosync) buf ^= 1;
     }
+    trc.flush(wave, ntl);
     l = group_sum(l);
     if (q < p.Tq) {
         const float inv = (DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f) / l;

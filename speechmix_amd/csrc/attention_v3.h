@@ -16,6 +16,11 @@
 #pragma once
 
 #define A3_MAXT 8
+// first pass: the workgroup meets once per A3_SYNC_EVERY tiles' fills (a barrier per tile cost ~900 cycles per tile: the two waves of a SIMD
+// alternate, and every meeting waits for the partner's whole tile - tools/gpu_attn_trace.py)
+#ifndef A3_SYNC_EVERY
+#define A3_SYNC_EVERY 8
+#endif
 typedef __attribute__((ext_vector_type(4))) int a3_rsrc_t;
 __device__ __forceinline__ a3_rsrc_t a3_make_rsrc(const void* base, unsigned bytes) {
     const unsigned long long b = (unsigned long long)base;
@@ -98,6 +103,8 @@ __global__ __launch_bounds__(NW * 64) void attn3_fwd(SmxAttnParams p, int np) {
     const int coff = p.Tk - p.Tq;
     const int tk = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
     constexpr int IC = NW == 16 ? 1 : 2;           // fills per tile and wave
+    A2Trace trc;
+    int ntl = 0;
     for (int ps = 0; ps < np; ++ps) {
         const int q0w = xb * chunk + (ps * NW + wave) * 16;          // my wave's first query
         const int q = q0w + i16;
@@ -123,15 +130,18 @@ __global__ __launch_bounds__(NW * 64) void attn3_fwd(SmxAttnParams p, int np) {
             a3_fill<NW>(lds0, lds0 + nt * 8192, rk, rv, p.k_ld, p.v_ld, nt, wave, lane);
         }
         const int tend = ps == 0 ? nt : (kend + 63) >> 6;
+        if (ps == 0) A2_TR_START(trc);
         for (int t = 0; t < tend; ++t) {
             const int k0 = t * 64;
-            if (ps == 0) a3_wait_tile((nt - 1 - t) * IC);
+            if (ps == 0 && (t & (A3_SYNC_EVERY - 1)) == 0) a3_wait_tile(max(nt - A3_SYNC_EVERY - t, 0) * IC);
             if (k0 >= kend) continue;
             if constexpr (DROP) mw = mk.tile(t, lane);
             const bool masked = (k0 + 64 > tk) || (CAUSAL && k0 + 63 > q0w + coff);
-            if (masked) a2_fwd_tile<true, BIAS, CAUSAL, DROP>(p, sK + t * 8192, sV + t * 8192, qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk);
-            else a2_fwd_tile<false, BIAS, CAUSAL, DROP>(p, sK + t * 8192, sV + t * 8192, qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk);
+            if (masked) a2_fwd_tile<true, BIAS, CAUSAL, DROP>(p, sK + t * 8192, sV + t * 8192, qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk, &trc);
+            else a2_fwd_tile<false, BIAS, CAUSAL, DROP>(p, sK + t * 8192, sV + t * 8192, qf, o, m, l, k0, q, h, lane, sl2, coff, mw, tk, &trc);
+            ++ntl;
         }
+        if (ps == np - 1) trc.flush(wave, ntl);
         l = group_sum(l);
         if (q < p.Tq) {
             const float inv = (DROP ? 1.0f / (1.0f - p.drop_p) : 1.0f) / l;
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void attn3_dq(SmxAttnParams p, int np) {
         const int tend = ps == 0 ? nt : (kend + 63) >> 6;
         for (int t = 0; t < tend; ++t) {
             const int k0 = t * 64;
-            if (ps == 0) a3_wait_tile((nt - 1 - t) * IC);
+            if (ps == 0 && (t & (A3_SYNC_EVERY - 1)) == 0) a3_wait_tile(max(nt - A3_SYNC_EVERY - t, 0) * IC);
             if (k0 >= kend) continue;
             if constexpr (DROP) mw = mk.tile(t, lane);
             const bool masked = (k0 + 64 > tk) || (q0w + 16 > p.Tq) || (CAUSAL && k0 + 63 > q0w + coff);
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void attn3_dkv(SmxAttnParams p, int np) {
         }
         for (int t = ps == 0 ? 0 : tbeg; t < nt; ++t) {
             const int q0 = t * 64;
-            if (ps == 0) a3_wait_tile((nt - 1 - t) * IC);
+            if (ps == 0 && (t & (A3_SYNC_EVERY - 1)) == 0) a3_wait_tile(max(nt - A3_SYNC_EVERY - t, 0) * IC);
             if (t < tbeg || !live) continue;
             if constexpr (DROP) mw = mk.tile(t, lane);
             const bool masked = (q0 + 64 > p.Tq) || (kb0w + 16 > tk) || (CAUSAL && kb0w + 15 > q0 + coff);
