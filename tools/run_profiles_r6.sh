@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-5 profile artefacts, one gpurun call:   gpurun --timeout 2700 -- bash tools/run_profiles_r5.sh
-# Writes under gpurun_out/r5prof/ ; the summaries are copied to profiles/r05_* by hand after the run.
+# Round-6 profile artefacts, one gpurun call:   gpurun --timeout 2700 -- bash tools/run_profiles_r6.sh
+# Writes under gpurun_out/r6prof/ ; the summaries are copied to profiles/r06_* by hand after the run.
 # (rocprofv3: the program itself after `--`, never a wrapper; PMC passes are separate runs with --kernel-trace only.
 #  The profiled passes run with SMX_STEP_GRAPHS=0: under the profiler the eager host is slower than the GPU, so the `auto` trial
 #  would pick the replayed step there and the kernel table would describe another schedule than the bench line's.)
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/r5prof
+O=gpurun_out/r6prof
 mkdir -p $O
 export TMPDIR=/tmp SMX_TUNE_FILE=$PWD/$O/tune.json
 # 1. the bench line (also fills the tuner file so that every later pass launches the same kernels)
@@ -45,7 +45,16 @@ F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 Q=$(find $O/pmc_sq -name "*counter_collection.csv" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_traffic.py "$F" "$W" $O/gemm_bytes_log.json > $O/pmc.json 2> $O/pmc.err
+[ -s $O/pmc.json ] && python3 -c "
+import json,sys,os
+p=sys.argv[1]; d=json.load(open(p)); d['tree']='tree '+os.environ.get('SMX_TREE','unknown')+' (round 6)'; json.dump(d,open(p,'w'),indent=1)" $O/pmc.json
 [ -n "$Q" ] && python3 tools/pmc_mfma.py "$Q" > $O/pmc_mfma.json 2> $O/pmc_mfma.err
 # the raw traces are large: keep the summaries only
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq
+# 5. round-6 kernels: GEMM timelines (free-running vs wave-specialised), attention phase trace and microbench
+tools/lab/build_variant.sh frtrace gemm_fr.hip "-DSMX_FR_TRACE=1 -DSMX_TU=gemm_fr" > /dev/null 2>&1
+SMX_LIB=tools/lab/libsmx_frtrace.so SMX_TL_MODES=13:192 timeout 300 python3 tools/gpu_fr_timeline.py > $O/fr_timeline.txt 2>&1
+SMX_ATTN_V3=0 timeout 200 python3 tools/gpu_attn_bench.py > $O/attn_v2.txt 2>&1
+SMX_ATTN_V3=1 timeout 200 python3 tools/gpu_attn_bench.py > $O/attn_v3.txt 2>&1
+timeout 300 python3 tools/gpu_ws_check.py time > $O/ws_time.txt 2>&1
 ls -la $O
