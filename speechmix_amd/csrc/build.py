@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "_obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("SMX_DEFS"):        # extra -D switches for A/B builds, comma separated
     FLAGS += ["-D" + d for d in os.environ["SMX_DEFS"].split(",")]
-if os.environ.get("SMX_PP_LAB"):      # ablation variants of the ping-pong GEMM (tools/gpu_pp_ksweep.py)
+if os.environ.get("SMX_PP_LAB"):      # ablation variants of the ping-pong GEMM (lab builds)
     FLAGS.append("-DSMX_PP_LAB")
 
 
