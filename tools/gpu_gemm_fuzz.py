@@ -23,7 +23,7 @@ for case in range(cases):
     S = torch.randn(M, N, device=dev).bfloat16()
     kind = rng.choice(["fwd", "fwd_act", "fwd_saved", "dgrad", "dgrad_actgrad", "dgrad_saved", "wgrad"])
     outs = {}
-    for mode in (1, 8, 12, 13, 12, 13):
+    for mode in (1, 8, 12, 13, 14, 12, 13, 14):
         try:
             if kind == "wgrad":
                 dY = S
