@@ -154,6 +154,9 @@ struct A2Trace { __device__ __forceinline__ void flush(int, int) {} };
 #define A2_TR_MARK(tr, i) do { } while (0)
 #endif
 
+#ifndef A2_FWD_OCC          // waves per SIMD the forward kernel is compiled for
+#define A2_FWD_OCC(BIAS, DROP) ((BIAS) ? 2 : 3)          // (round 6: the dropout variants fit 168 registers too - 0 / 12 bytes of scratch)
+#endif
 // ---------------------------------------------------------------- forward
 template <bool MASKED, bool BIAS, bool CAUSAL, bool DROP>
 __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* tK, const char* tV, const bf16x8_t (&qf)[2],
@@ -253,7 +256,7 @@ __device__ __forceinline__ void a2_fwd_tile(const SmxAttnParams& p, const char* 
 }
 
 template <bool BIAS, bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256, (BIAS || DROP) ? 2 : 3) void attn2_fwd(SmxAttnParams p) {
+__global__ __launch_bounds__(256, A2_FWD_OCC(BIAS, DROP)) void attn2_fwd(SmxAttnParams p) {
     __shared__ __attribute__((aligned(16))) char sK[2][8192];
     __shared__ __attribute__((aligned(16))) char sV[2][8192];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
