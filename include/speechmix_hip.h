@@ -242,6 +242,11 @@ typedef struct SmxAfParams {
 /* racc / cacc / cpart / usq_part / gsq_part are STORE-ONLY scratch (every element read was stored by exactly one tile of the same
  * step): the caller need not zero them; no atomics anywhere in the step. */
 int smx_adafactor_step(const SmxAfParams* p, hipStream_t stream);
+/* The same step in phases (round 6): phase 0 = statistics pass over every tile + global norm + partial folds (no update); phase 1 = the two
+ * update passes over tiles tile_first .. tile_first + tile_count - 1 (whole tensors).  Phase 0 followed by phase-1 calls covering every tile
+ * once equals smx_adafactor_step bit for bit; the host may put the later ranges on another stream (the optimizer's tail beside the next
+ * step's front end - what HF Trainer's optimizer.step() of TF:trainer.py cannot do). */
+int smx_adafactor_phase(const SmxAfParams* p, int phase, int tile_first, int tile_count, hipStream_t stream);
 
 /* Data-parallel gradient reduction: in-place sum-all-reduce of one contiguous bucket of the flat
  * gradient buffer over RCCL, on the caller's (side) stream - what HF Trainer -> accelerate -> DistributedDataParallel's

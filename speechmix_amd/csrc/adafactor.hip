@@ -303,9 +303,10 @@ __global__ __launch_bounds__(256) void af_fold_kernel(SmxAfParams o) {
 
 // ---- rms / apply ---------------------------------------------------------------------------------------------------
 template <bool APPLY>
-__global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o) {
+__global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o, int tile0) {
     __shared__ float sh[16];
-    const SmxAfTile tl = o.tiles[blockIdx.x];
+    const int tix = blockIdx.x + tile0;          // (a ranged launch - smx_adafactor_phase - covers tiles tile0 .. tile0 + gridDim.x - 1)
+    const SmxAfTile tl = o.tiles[tix];
     const SmxAfTensor T = o.tensors[tl.tensor];
     if (o.beta2t[tl.tensor] < 0.f) return;
     const float gs = af_gscale(o);
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o) {
                 s1 += u * u;
             }
             s1 = block_sum(s1, sh);
-            if (threadIdx.x == 0) o.usq_part[blockIdx.x] = s1;
+            if (threadIdx.x == 0) o.usq_part[tix] = s1;
             return;
         }
         const float* v = o.col + T.col_off;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void af_update_kernel(SmxAfParams o) {
     }
     if (!APPLY) {
         s = block_sum(s, sh);
-        if (threadIdx.x == 0) o.usq_part[blockIdx.x] = s;
+        if (threadIdx.x == 0) o.usq_part[tix] = s;
     }
 }
 
@@ -435,9 +436,35 @@ extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
     hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
     if (o.max_grad_norm > 0.f) hipLaunchKernelGGL(af_gnorm_kernel, dim3(1), dim3(1024), 0, stream, o);
     if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
-    hipLaunchKernelGGL(af_update_kernel<false>, dim3(o.ntiles), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_update_kernel<false>, dim3(o.ntiles), dim3(256), 0, stream, o, 0);
     hipLaunchKernelGGL(af_usq_kernel, dim3((o.ntensors + 3) / 4), dim3(256), 0, stream, o);
-    hipLaunchKernelGGL(af_update_kernel<true>, dim3(o.ntiles), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_update_kernel<true>, dim3(o.ntiles), dim3(256), 0, stream, o, 0);
+    SMX_CHECK_LAUNCH();
+}
+
+// The same step in phases (round 6: the optimizer's tail beside the next step's front end, trainer.py):
+//   phase 0: the statistics pass over EVERY tile, the global gradient norm and the fold of the column / row partials - nothing is updated;
+//   phase 1: the two update passes (per-tensor RMS of the update, then the parameters) over the tiles tile_first .. tile_first + tile_count - 1,
+//            which must be whole tensors (a tensor's tiles are contiguous); the per-tensor sums between them run over all tensors - a tensor
+//            outside the range gets a sum of stale partials that its own phase-1 call recomputes before it is used.
+// phase 0 followed by phase-1 calls that cover every tile exactly once = smx_adafactor_step, bit for bit (same kernels, same order per tensor).
+extern "C" int smx_adafactor_phase(const SmxAfParams* op, int phase, int tile_first, int tile_count, hipStream_t stream) {
+    (void)hipGetLastError();
+    SmxAfParams o = *op;
+    if (o.ntiles <= 0 || o.ntensors <= 0) return SMX_OK;
+    if (!o.p || !o.g || !o.tensors || !o.tiles || !o.segs || !o.row || !o.col || !o.racc || !o.cacc || !o.rmean || !o.usq ||
+        !o.usq_part || !o.cpart || !o.beta2t || !o.gsq_part || !o.gn2) return SMX_EINVAL;
+    if (phase == 0) {
+        hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
+        if (o.max_grad_norm > 0.f) hipLaunchKernelGGL(af_gnorm_kernel, dim3(1), dim3(1024), 0, stream, o);
+        if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
+        SMX_CHECK_LAUNCH();
+    }
+    if (phase != 1 || tile_first < 0 || tile_count < 0 || tile_first + tile_count > o.ntiles) return SMX_EINVAL;
+    if (tile_count == 0) return SMX_OK;
+    hipLaunchKernelGGL(af_update_kernel<false>, dim3(tile_count), dim3(256), 0, stream, o, tile_first);
+    hipLaunchKernelGGL(af_usq_kernel, dim3((o.ntensors + 3) / 4), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_update_kernel<true>, dim3(tile_count), dim3(256), 0, stream, o, tile_first);
     SMX_CHECK_LAUNCH();
 }
 

@@ -1543,6 +1543,8 @@ class Engine:
         act = _act_id(ec.hidden_act)
         sv["layers"] = []
         hidden = [x]
+        if self._cap is None:
+            self.wait_params()          # (the front end above reads front-end tensors only; a replayed step waits between its graphs)
         for i in range(self.L):
             self._seg("front" if i == 0 else f"enc_fwd{i - 1}")
             self._note(**{f"fwd_in{i}": x})
@@ -2449,6 +2451,15 @@ class Engine:
             ops.IN_BACKWARD = False
             if self.folds is not None:
                 self.folds.items.clear()
+
+    def wait_params(self):
+        """The parameters beyond the front end may still be under the previous optimizer step's tail on a second stream (trainer.py,
+        SMX_OPT_OVERLAP): the current stream waits for it here - before the first encoder layer of a forward, and wherever else parameters
+        are read."""
+        ev = getattr(self, "param_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.param_event = None
 
     def note_dropped(self, zeroed):
         """Called after every backward (eager or replayed) with `last_dropped` of its forward."""

@@ -270,6 +270,8 @@ class StepGraphs:
                         cb(name[6:])
                     continue
             g.replay()
+            if name == "front":
+                eng.wait_params()          # the optimizer's tail of the previous step (trainer.py): complete before the first encoder layer
             if tr is not None:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()

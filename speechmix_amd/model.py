@@ -397,6 +397,9 @@ class SpeechMixEED(nn.Module):
         return [g for g in groups.values() if len(g) > 1]
 
     def state_dict(self, *args, **kwargs):
+        eng = self.__dict__.get("engine")
+        if eng is not None:
+            eng.wait_params()          # (an optimizer tail still running on its second stream: trainer.py SMX_OPT_OVERLAP)
         sd = super().state_dict(*args, **kwargs)
         if not self.tied_aliases_in_state_dict:
             prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")

@@ -939,6 +939,7 @@ class AdafactorPlan:
                                                ("col_off", "<i4"), ("rm_off", "<i4"), ("factored", "<i4"), ("tile0", "<i4"),
                                                ("ntile", "<i4"), ("_pad", "<i4")]))
         assert tt.dtype.itemsize == C.sizeof(L.AfTensor)
+        self._tt_dtype = tt.dtype
         # tiles: (tensor, b, r0, nr, c0, nc, full_rows, full_cols, cp_off, rp_off); segs: (tensor, b, cp_off, n_rt, rp_off, n_ct).
         # Every reduction of the step has a fixed order (csrc/adafactor.hip): a row tile owns row `rt` of its segment's [n_rt][C]
         # block of column partials (cp_off), a column tile row `ct` of its [n_ct][R] block of row sums (rp_off), the fold adds them
@@ -1013,7 +1014,7 @@ class AdafactorPlan:
         self._b2_i = 0
 
     def step(self, p, g, shadow, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
-             max_grad_norm=0.0):
+             max_grad_norm=0.0, split=None, tail_stream=None):
         """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched).
         max_grad_norm > 0: global-norm clipping (HF Trainer's clip_grad_norm_ before optimizer.step); the norm comes out of the
         step's own statistics pass over the gradient."""
@@ -1040,8 +1041,35 @@ class AdafactorPlan:
         o.racc_n, o.cacc_n, o.ntensors, o.ntiles, o.nsegs = self.row_n, self.col_n, self.n, self.ntiles, self.nsegs
         o.lr, o.eps1, o.clip_threshold, o.grad_scale, o.max_grad_norm = lr, eps1, clip_threshold, grad_scale, max_grad_norm
         nact = float(sum(t[1] for t, a in zip(self._numel, act) if a)) if hasattr(self, "_numel") else 0.0
-        with _Span("adafactor_step", 22.0 * nact):       # g read 3x, p read + written, bf16 copy written (csrc/adafactor.hip)
-            L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
+        if split is None:
+            with _Span("adafactor_step", 22.0 * nact):       # g read 3x, p read + written, bf16 copy written (csrc/adafactor.hip)
+                L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
+            return None
+        # Phased form: statistics over everything and the update of tensors split = (first, last) - a contiguous range of the constructor's
+        # order - on the current stream; the update of all the others on `tail_stream` behind them.  -> the event after which every parameter is final.
+        t_a, t_b = int(self.tile0_of(split[0])), int(self.tile0_of(split[1]))
+        lib = L.lib()
+        with _Span("adafactor_step", 22.0 * nact):
+            L.check(lib.smx_adafactor_phase(C.byref(o), 0, 0, 0, _stream()), "smx_adafactor_phase")
+            L.check(lib.smx_adafactor_phase(C.byref(o), 1, t_a, t_b - t_a, _stream()), "smx_adafactor_phase")
+        ev0 = torch.cuda.Event()
+        ev0.record()
+        tail_stream.wait_event(ev0)
+        with torch.cuda.stream(tail_stream):
+            if t_a > 0:
+                L.check(lib.smx_adafactor_phase(C.byref(o), 1, 0, t_a, _stream()), "smx_adafactor_phase")
+            if t_b < self.ntiles:
+                L.check(lib.smx_adafactor_phase(C.byref(o), 1, t_b, self.ntiles - t_b, _stream()), "smx_adafactor_phase")
+            done = torch.cuda.Event()
+            done.record()
+        return done
+
+    def tile0_of(self, t):
+        """First tile of tensor t (tensors in the order given to the constructor); t == n: the tile count."""
+        if not hasattr(self, "_tile0"):
+            tt = self.tensors.cpu().numpy().view(self._tt_dtype)
+            self._tile0 = [int(x) for x in tt["tile0"]] + [self.ntiles]
+        return self._tile0[t]
 
 
 def act_bwd(dy, pre, dx, M, N, out_view, act, dtype):

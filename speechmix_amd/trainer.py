@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -94,6 +96,16 @@ class StepRunner:
             self.af_names = [nm for nm, _ in sorted(self.store.offsets.items(), key=lambda kv: kv[1][0])]
             self.af = ops.AdafactorPlan([(self.store.offsets[nm][0], self.store.offsets[nm][2]) for nm in self.af_names], dev)
             self._af_layer = [self.layer_of[nm] for nm in self.af_names]
+            # The optimizer's tail beside the next step's front end (round 6): the statistics pass and the update of the
+            # FRONT-END tensors (waveform CNN, feature projection, positional conv, the encoder's input LayerNorm - a contiguous range of the flat order)
+            # stay on the compute stream, the update of everything else goes to a second stream and has to be complete only when the next
+            # forward reaches its first encoder layer (Engine.wait_params: eager and replayed steps, and every other reader of parameters).
+            # SMX_OPT_OVERLAP=0: off.
+            front = [nm.startswith(ep) and not nm.startswith(pre) for nm in self.af_names]
+            idx = [i for i, f in enumerate(front) if f]
+            self._af_split = (idx[0], idx[-1] + 1) if (os.environ.get("SMX_OPT_OVERLAP", "1") != "0" and dev.type == "cuda" and idx
+                                                      and len(idx) == idx[-1] + 1 - idx[0] and len(idx) < len(front)) else None
+            self._opt_stream = None
         self._flags = None
         self._force_comm = force_comm
         self.use_graphs = True           # (see _step_graphs)
@@ -200,6 +212,11 @@ class StepRunner:
         else:
             self._graph_choice[key] = "replay"
 
+    def sync_params(self):
+        """Make the current stream wait for an optimizer tail that is still running on the second stream (anything that reads parameters
+        outside Engine.forward - a checkpoint, an evaluation loop of another object - calls this or synchronises the device)."""
+        self.engine.wait_params()
+
     def current_lr(self):
         return float(self.lr(self.t)) if callable(self.lr) else float(self.lr)
 
@@ -262,8 +279,14 @@ class StepRunner:
         dropped = self._dropped_all if self.world == 1 else set()
         if self.af is not None:
             active = [f and (l not in dropped) for f, l in zip((st.requires_grad(nm) for nm in self.af_names), self._af_layer)]
-            self.af.step(st.master, st.grad, sh, lr, active=active,
-                         grad_scale=inv_world, max_grad_norm=clip)
+            if self._af_split is not None:
+                if self._opt_stream is None:
+                    self._opt_stream = torch.cuda.Stream()
+                eng.param_event = self.af.step(st.master, st.grad, sh, lr, active=active, grad_scale=inv_world, max_grad_norm=clip,
+                                               split=self._af_split, tail_stream=self._opt_stream)
+            else:
+                self.af.step(st.master, st.grad, sh, lr, active=active,
+                             grad_scale=inv_world, max_grad_norm=clip)
             st.mark_shadow_fresh()
             if trial is not None:          # (the WHOLE step: forward + backward alone favoured the replay by up to 1.8 ms on steps that then tied)
                 ev[1].record()

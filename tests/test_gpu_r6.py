@@ -301,3 +301,76 @@ def test_capture_abort_behind_a_fork_leaves_no_stream_capturing():
     del r, m, eng
     gc.collect()
     torch.cuda.synchronize()
+
+
+def test_optimizer_tail_beside_the_next_front_end_changes_no_bit():
+    """SMX_OPT_OVERLAP (default on): Adafactor's statistics pass and the update of the front-end tensors on the compute stream, the update of
+    every other tensor on a second stream that the next forward joins before its first encoder layer.  (a) The phased step against the
+    one-launch-sequence step from the SAME parameters, gradients and optimizer state: identical parameters, compute copies and second-moment
+    factors, three steps in a row (same kernels per tensor in the same order; only the streams differ).  (b) Through StepRunner, eager and
+    replayed: the training runs (which differ run to run in the last bits anyway - fp32 atomics ahead of Adafactor's g / RMS(g)) stay
+    together, and a state_dict() right after a step, without a device synchronisation, sees the final parameters."""
+    import contextlib, io
+    from speechmix_amd import graphs, ops
+    from speechmix_amd.model import SpeechMixEED
+    from speechmix_amd.trainer import StepRunner
+    from tests.test_gpu_r5 import ENC, LM
+    dev = torch.device("cuda:0")
+    # (a) plan level
+    torch.manual_seed(1)
+    shapes = [(64, 10), (64,), (128, 64, 3), (128,), (300, 520), (520,), (1000, 128), (77,), (2048, 256), (256, 2048)]
+    offs, off = [], 0
+    for sh in shapes:
+        n = 1
+        for d in sh:
+            n *= d
+        offs.append((off, sh))
+        off = (off + n + 63) // 64 * 64
+    plans = [ops.AdafactorPlan(offs, dev) for _ in range(2)]
+    p = [torch.randn(off, device=dev) * 0.1 for _ in range(2)]
+    p[1].copy_(p[0])
+    sh16 = [x.bfloat16() for x in p]
+    side = torch.cuda.Stream()
+    active = [True] * len(shapes)
+    active[3] = False
+    for step in range(3):
+        g = torch.randn(off, device=dev) * (0.5 + step)
+        plans[0].step(p[0], g, sh16[0], 1e-2, active=active, max_grad_norm=1.0)
+        done = plans[1].step(p[1], g, sh16[1], 1e-2, active=active, max_grad_norm=1.0, split=(2, 6), tail_stream=side)
+        assert done is not None
+        torch.cuda.current_stream().wait_event(done)
+        torch.cuda.synchronize()
+        assert torch.equal(p[0], p[1]) and torch.equal(sh16[0], sh16[1]), step
+        assert torch.equal(plans[0].row, plans[1].row) and torch.equal(plans[0].col, plans[1].col) and torch.equal(plans[0].rmean, plans[1].rmean)
+    assert plans[1].tile0_of(0) == 0 and plans[1].tile0_of(len(shapes)) == plans[1].ntiles
+
+    # (b) through the runner
+    def run(overlap, use_graphs):
+        graphs.MODE, graphs.ENABLED = "1", True
+        g = torch.Generator().manual_seed(0)
+        wave = (torch.randn(4, 12000, generator=g) * 0.1).cuda()
+        labels = torch.randint(4, 200, (4, 6), generator=g).cuda()
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = SpeechMixEED(ENC, LM, down_scale=2, compute_dtype="bf16", init_seed=0).train()
+        r = StepRunner(m, lr=1e-3, optimizer="adafactor", max_grad_norm=1.0, seed=5)
+        if not overlap:
+            r._af_split = None
+        else:
+            assert r._af_split is not None and r._af_split[1] - r._af_split[0] < len(r.af_names)
+            assert all(n.startswith("encoder_model.") and ".encoder.layers." not in n for n in r.af_names[r._af_split[0]:r._af_split[1]])
+        r.use_graphs = use_graphs
+        losses = []
+        for s in range(8):
+            losses.append(float(r.step(wave, labels).item()))
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}          # (no device synchronisation before it, on purpose)
+        torch.cuda.synchronize()
+        return losses, sd, m
+    for use_graphs in (False, True):
+        l0, _, _ = run(False, use_graphs)
+        l1, sd, m = run(True, use_graphs)
+        assert all(abs(a - b) <= 0.05 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (use_graphs, l0, l1)
+        assert l1[-1] < l1[0]
+        own = dict(m.named_parameters())
+        for k, v in sd.items():
+            if k in own:
+                assert torch.equal(v, own[k].detach()), k
