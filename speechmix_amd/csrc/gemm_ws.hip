@@ -11,8 +11,9 @@
 //   waves 0..11  compute: 3 x 4 wave tiles of 64 x 64 (64 accumulator registers, six A fragment slots + four B fragments),
 //                three per SIMD; per K tile 32 MFMAs (16x16x32) and 16 fragment reads each, no VMEM instruction in the loop;
 //   waves 12..15 loaders: one per SIMD, raised priority; each issues 14 (16 with a rows-contiguous A) of the K tile's 56 (64)
-//                LDS-DMA instructions - two of the eight 1-KB pieces of every pass of every unit -, decodes the work list,
-//                re-targets the operand descriptors at item boundaries and fetches the item's bias slice.
+//                LDS-DMA instructions - two of the eight 1-KB pieces of every pass of every unit -, decodes the work list ONE ITEM AHEAD
+//                (in two steps spread over two K tiles' slack), writes the item's record and fetches its bias slice into LDS
+//                (four slots each): the compute waves read their item from LDS instead of decoding it themselves.
 //
 // Same flat unit stream as the other 256-wide kernels (two 64-KB stages, the stream runs across work items, so an item's first two
 // K tiles are in flight / resident while the previous item's epilogue runs) and ONE workgroup barrier per K tile:
@@ -413,7 +414,7 @@ static void ws_launch(const SmxGemmParams& p, dim3 grid, hipStream_t stream) {
 }
 
 // tr_mode 14: 192 x 256 tiles, twelve compute + four loader waves.  Instantiated for the layouts / classes of the free-running kernel;
-// every K slice must hold at least two K tiles (the bias slots, above); batched views of rows-contiguous operands are refused
+// one-tile items included (four bias / record slots: the loader is at most two items ahead); batched views of rows-contiguous operands are refused
 // (the tuner never offers them).
 int smx_gemm_ws(const SmxGemmParams& pin, hipStream_t stream) {
     SmxGemmParams p = pin;
