@@ -477,6 +477,11 @@ def main():
                                  "the timed region); forward + backward replayed from captured HIP graphs when step_graphs is true "
                                  "(speechmix_amd/graphs.py; mode auto: the set-up times 3 replayed and 3 eager steps - "
                                  "trial_fwd_bwd_ms - and keeps the faster)"}}
+        if getattr(runner, "_af_split", None) is not None:
+            line["optimizer_overlap"] = {"front_end_tensors": runner._af_split[1] - runner._af_split[0], "tensors": len(runner.af_names),
+                                         "note": "Adafactor: statistics pass + the front-end tensors' update on the compute stream (other_kernels."
+                                                 "adafactor_stats_and_front), the update of every other tensor on a second stream beside the next step's "
+                                                 "front end, joined before its first encoder layer (SMX_OPT_OVERLAP=0: one stream)"}
         if in_sync is not None:
             line["params_in_sync"] = in_sync
         if trainer_path is not None:

@@ -1049,7 +1049,8 @@ class AdafactorPlan:
         # order - on the current stream; the update of all the others on `tail_stream` behind them.  -> the event after which every parameter is final.
         t_a, t_b = int(self.tile0_of(split[0])), int(self.tile0_of(split[1]))
         lib = L.lib()
-        with _Span("adafactor_step", 22.0 * nact):
+        # (op profile: the compute stream's share only - the statistics pass reads every gradient once; the tail runs on `tail_stream`)
+        with _Span("adafactor_stats_and_front", 4.0 * nact):
             L.check(lib.smx_adafactor_phase(C.byref(o), 0, 0, 0, _stream()), "smx_adafactor_phase")
             L.check(lib.smx_adafactor_phase(C.byref(o), 1, t_a, t_b - t_a, _stream()), "smx_adafactor_phase")
         ev0 = torch.cuda.Event()
