@@ -243,7 +243,8 @@ typedef struct SmxAfParams {
  * step): the caller need not zero them; no atomics anywhere in the step. */
 int smx_adafactor_step(const SmxAfParams* p, hipStream_t stream);
 /* The same step in phases (round 6): phase 0 = statistics pass over every tile + global norm + partial folds (no update); phase 1 = the two
- * update passes over tiles tile_first .. tile_first + tile_count - 1 (whole tensors).  Phase 0 followed by phase-1 calls covering every tile
+ * update passes over tiles tile_first .. tile_first + tile_count - 1 (whole tensors); phase 2 = the statistics pass over a tile range, phase 3 = global
+ * norm + partial folds behind phase-2 calls that covered every tile (0 = 2 over everything + 3).  Phase 0 followed by phase-1 calls covering every tile
  * once equals smx_adafactor_step bit for bit; the host may put the later ranges on another stream (the optimizer's tail beside the next
  * step's front end - what HF Trainer's optimizer.step() of TF:trainer.py cannot do). */
 int smx_adafactor_phase(const SmxAfParams* p, int phase, int tile_first, int tile_count, hipStream_t stream);

@@ -80,10 +80,11 @@ __device__ __forceinline__ float af_clip(const SmxAfParams& o) {
 __device__ __forceinline__ float af_gscale(const SmxAfParams& o) { return o.grad_scale * af_clip(o); }
 
 // ---- stats: u0 = (grad_scale g)^2 summed along rows and columns, and over the tile --------------------------------------
-__global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
+__global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o, int tile0) {
     __shared__ float cpart[4][AF_MAXC];
     __shared__ float wsum[4];
-    const SmxAfTile tl = o.tiles[blockIdx.x];
+    const int tix = blockIdx.x + tile0;          // (a ranged launch - smx_adafactor_phase - covers tiles tile0 .. tile0 + gridDim.x - 1)
+    const SmxAfTile tl = o.tiles[tix];
     const SmxAfTensor T = o.tensors[tl.tensor];
     const float gs = o.grad_scale;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
             s *= gs * gs;
         }
         s = block_sum(s, &cpart[0][0]);
-        if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = s;
+        if (threadIdx.x == 0) o.gsq_part[tix] = s;
         return;
     }
     if (!T.factored) {               // 1-D: only the tile's sum of squares here (v and sum upd^2: the rms launch, once the norm is known)
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
             s += gi * gi;
         }
         s = block_sum(s, &cpart[0][0]);
-        if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = s;
+        if (threadIdx.x == 0) o.gsq_part[tix] = s;
         return;
     }
     float* racc = o.racc + T.row_off + (long long)tl.b * T.R;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
         }
         __syncthreads();
         tot = block_sum(tot, &cpart[0][0]);
-        if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = tot;
+        if (threadIdx.x == 0) o.gsq_part[tix] = tot;
         return;
     }
     // wide: wave w takes rows r0 + w, + 4 ...; a lane takes 4 consecutive columns c0 + 4 (lane + 64 j) (16-B loads when
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void af_stats_kernel(SmxAfParams o) {
     }
     if (lane == 0) wsum[w] = wtot;
     __syncthreads();
-    if (threadIdx.x == 0) o.gsq_part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) o.gsq_part[tix] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // ---- gnorm: sum (grad_scale g)^2 over all tiles, in tile order -----------------------------------
@@ -433,7 +434,7 @@ extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
     if (o.ntiles <= 0 || o.ntensors <= 0) return SMX_OK;
     if (!o.p || !o.g || !o.tensors || !o.tiles || !o.segs || !o.row || !o.col || !o.racc || !o.cacc || !o.rmean || !o.usq ||
         !o.usq_part || !o.cpart || !o.beta2t || !o.gsq_part || !o.gn2) return SMX_EINVAL;
-    hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
+    hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o, 0);
     if (o.max_grad_norm > 0.f) hipLaunchKernelGGL(af_gnorm_kernel, dim3(1), dim3(1024), 0, stream, o);
     if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
     hipLaunchKernelGGL(af_update_kernel<false>, dim3(o.ntiles), dim3(256), 0, stream, o, 0);
@@ -443,7 +444,8 @@ extern "C" int smx_adafactor_step(const SmxAfParams* op, hipStream_t stream) {
 }
 
 // The same step in phases (round 6: the optimizer's tail beside the next step's front end, trainer.py):
-//   phase 0: the statistics pass over EVERY tile, the global gradient norm and the fold of the column / row partials - nothing is updated;
+//   phase 0: the statistics pass over EVERY tile, the global gradient norm and the fold of the column / row partials - nothing is updated
+//            (= phase 2 over every tile + phase 3);
 //   phase 1: the two update passes (per-tensor RMS of the update, then the parameters) over the tiles tile_first .. tile_first + tile_count - 1,
 //            which must be whole tensors (a tensor's tiles are contiguous); the per-tensor sums between them run over all tensors - a tensor
 //            outside the range gets a sum of stale partials that its own phase-1 call recomputes before it is used.
@@ -455,13 +457,23 @@ extern "C" int smx_adafactor_phase(const SmxAfParams* op, int phase, int tile_fi
     if (!o.p || !o.g || !o.tensors || !o.tiles || !o.segs || !o.row || !o.col || !o.racc || !o.cacc || !o.rmean || !o.usq ||
         !o.usq_part || !o.cpart || !o.beta2t || !o.gsq_part || !o.gn2) return SMX_EINVAL;
     if (phase == 0) {
-        hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o);
+        hipLaunchKernelGGL(af_stats_kernel, dim3(o.ntiles), dim3(256), 0, stream, o, 0);
         if (o.max_grad_norm > 0.f) hipLaunchKernelGGL(af_gnorm_kernel, dim3(1), dim3(1024), 0, stream, o);
         if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
         SMX_CHECK_LAUNCH();
     }
-    if (phase != 1 || tile_first < 0 || tile_count < 0 || tile_first + tile_count > o.ntiles) return SMX_EINVAL;
+    if (phase == 3) {          // the global norm and the partial folds: behind phase-2 calls that covered every tile
+        if (o.max_grad_norm > 0.f) hipLaunchKernelGGL(af_gnorm_kernel, dim3(1), dim3(1024), 0, stream, o);
+        if (o.nsegs > 0) hipLaunchKernelGGL(af_fold_kernel, dim3(o.nsegs), dim3(256), 0, stream, o);
+        SMX_CHECK_LAUNCH();
+    }
+    if ((phase != 1 && phase != 2) || tile_first < 0 || tile_count < 0 || tile_first + tile_count > o.ntiles) return SMX_EINVAL;
     if (tile_count == 0) return SMX_OK;
+    if (phase == 2) {          // the statistics pass over a tile range (whole tensors): gradients that are final early - the LM's and the
+                               // encoder layers' while the front end is still in backward - are read beside it on another stream
+        hipLaunchKernelGGL(af_stats_kernel, dim3(tile_count), dim3(256), 0, stream, o, tile_first);
+        SMX_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(af_update_kernel<false>, dim3(tile_count), dim3(256), 0, stream, o, tile_first);
     hipLaunchKernelGGL(af_usq_kernel, dim3((o.ntensors + 3) / 4), dim3(256), 0, stream, o);
     hipLaunchKernelGGL(af_update_kernel<true>, dim3(tile_count), dim3(256), 0, stream, o, tile_first);

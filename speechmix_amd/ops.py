@@ -1013,11 +1013,9 @@ class AdafactorPlan:
         self._b2_ev = [None] * 4
         self._b2_i = 0
 
-    def step(self, p, g, shadow, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
-             max_grad_norm=0.0, split=None, tail_stream=None):
-        """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched).
-        max_grad_norm > 0: global-norm clipping (HF Trainer's clip_grad_norm_ before optimizer.step); the norm comes out of the
-        step's own statistics pass over the gradient."""
+    def prepare(self, p, g, shadow, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0, max_grad_norm=0.0):
+        """Everything of a step ahead of its launches: per-tensor step counts, the decay factors' upload, the parameter block.
+        -> (parameter block, active element count).  Once per optimizer step."""
         np = self._np
         act = np.ones(self.n, dtype=bool) if active is None else np.asarray(active, dtype=bool)
         self.steps[act] += 1
@@ -1041,17 +1039,32 @@ class AdafactorPlan:
         o.racc_n, o.cacc_n, o.ntensors, o.ntiles, o.nsegs = self.row_n, self.col_n, self.n, self.ntiles, self.nsegs
         o.lr, o.eps1, o.clip_threshold, o.grad_scale, o.max_grad_norm = lr, eps1, clip_threshold, grad_scale, max_grad_norm
         nact = float(sum(t[1] for t, a in zip(self._numel, act) if a)) if hasattr(self, "_numel") else 0.0
-        if split is None:
-            with _Span("adafactor_step", 22.0 * nact):       # g read 3x, p read + written, bf16 copy written (csrc/adafactor.hip)
-                L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
-            return None
-        # Phased form: statistics over everything and the update of tensors split = (first, last) - a contiguous range of the constructor's
-        # order - on the current stream; the update of all the others on `tail_stream` behind them.  -> the event after which every parameter is final.
+        return o, nact
+
+    def early_stats(self, o, split):
+        """The statistics pass over every tensor OUTSIDE split = (first, last) on the current stream (gradients that are final before the
+        step's backward has ended); `finish(..., early=True)` does the rest."""
         t_a, t_b = int(self.tile0_of(split[0])), int(self.tile0_of(split[1]))
         lib = L.lib()
-        # (op profile: the compute stream's share only - the statistics pass reads every gradient once; the tail runs on `tail_stream`)
+        if t_a > 0:
+            L.check(lib.smx_adafactor_phase(C.byref(o), 2, 0, t_a, _stream()), "smx_adafactor_phase")
+        if t_b < self.ntiles:
+            L.check(lib.smx_adafactor_phase(C.byref(o), 2, t_b, self.ntiles - t_b, _stream()), "smx_adafactor_phase")
+
+    def finish(self, o, nact, split, tail_stream, early=False):
+        """The phased step: statistics (everything, or with early = True only tensors split = (first, last) - the others' were taken by
+        `early_stats` on `tail_stream`, which is joined here), global norm + folds and the update of the split range on the current stream;
+        the update of all the others on `tail_stream` behind them.  -> the event after which every parameter is final."""
+        t_a, t_b = int(self.tile0_of(split[0])), int(self.tile0_of(split[1]))
+        lib = L.lib()
+        # (op profile: the compute stream's share only - the statistics pass reads the gradients once; the tail runs on `tail_stream`)
         with _Span("adafactor_stats_and_front", 4.0 * nact):
-            L.check(lib.smx_adafactor_phase(C.byref(o), 0, 0, 0, _stream()), "smx_adafactor_phase")
+            if early:
+                L.check(lib.smx_adafactor_phase(C.byref(o), 2, t_a, t_b - t_a, _stream()), "smx_adafactor_phase")
+                torch.cuda.current_stream().wait_stream(tail_stream)
+                L.check(lib.smx_adafactor_phase(C.byref(o), 3, 0, 0, _stream()), "smx_adafactor_phase")
+            else:
+                L.check(lib.smx_adafactor_phase(C.byref(o), 0, 0, 0, _stream()), "smx_adafactor_phase")
             L.check(lib.smx_adafactor_phase(C.byref(o), 1, t_a, t_b - t_a, _stream()), "smx_adafactor_phase")
         ev0 = torch.cuda.Event()
         ev0.record()
@@ -1064,6 +1077,18 @@ class AdafactorPlan:
             done = torch.cuda.Event()
             done.record()
         return done
+
+    def step(self, p, g, shadow, lr, active=None, decay_rate=-0.8, eps1=1e-30, clip_threshold=1.0, grad_scale=1.0,
+             max_grad_norm=0.0, split=None, tail_stream=None):
+        """active: optional bool sequence per tensor; tensors without a gradient this step are skipped (state untouched).
+        max_grad_norm > 0: global-norm clipping (HF Trainer's clip_grad_norm_ before optimizer.step); the norm comes out of the
+        step's own statistics pass over the gradient.  split / tail_stream: the phased form (`finish`)."""
+        o, nact = self.prepare(p, g, shadow, lr, active, decay_rate, eps1, clip_threshold, grad_scale, max_grad_norm)
+        if split is None:
+            with _Span("adafactor_step", 22.0 * nact):       # g read 3x, p read + written, bf16 copy written (csrc/adafactor.hip)
+                L.check(L.lib().smx_adafactor_step(C.byref(o), _stream()), "smx_adafactor_step")
+            return None
+        return self.finish(o, nact, split, tail_stream)
 
     def tile0_of(self, t):
         """First tile of tensor t (tensors in the order given to the constructor); t == n: the tile count."""

@@ -88,6 +88,7 @@ class StepRunner:
         # speech-encoder layer index of every parameter (LayerDrop bookkeeping), -1 elsewhere
         self.layer_of = {nm: (int(nm[len(pre):].split(".", 1)[0]) if nm.startswith(pre) else -1) for nm in self.store.offsets}
         self.af = None
+        self._af_split, self._opt_stream, self._af_early, self._early_ok = None, None, None, False
         if optimizer == "adafactor":
             # the reference's optimizer (ref:train.py:298 -> HF Trainer: Adafactor(lr, scale_parameter=False,
             # relative_step=False)); one fused multi-tensor step over the flat buffer (csrc/adafactor.hip).  The plan covers
@@ -106,6 +107,7 @@ class StepRunner:
             self._af_split = (idx[0], idx[-1] + 1) if (os.environ.get("SMX_OPT_OVERLAP", "1") != "0" and dev.type == "cuda" and idx
                                                       and len(idx) == idx[-1] + 1 - idx[0] and len(idx) < len(front)) else None
             self._opt_stream = None
+            self._af_early, self._early_ok = None, False
         self._flags = None
         self._force_comm = force_comm
         self.use_graphs = True           # (see _step_graphs)
@@ -132,7 +134,7 @@ class StepRunner:
         self.reducer = GradReducer(self.store.grad, stage_ranges(self.store.offsets, self.model.num_speech_encoder_layers,
                                                                  trainable=self.store.requires_grad),
                                    force_comm=self._force_comm)
-        self.engine.stage_cb = self.reducer.stage_done
+        self.engine.stage_cb = self._stage_cb
         self.engine.stage_ranges = self.reducer.stages        # (ranges a reported stage hands to the reducer: Engine._stage)
 
     # ------------------------------------------------------------------ captured steps (graphs.py)
@@ -212,6 +214,31 @@ class StepRunner:
         else:
             self._graph_choice[key] = "replay"
 
+    def _stage_cb(self, name):
+        """Backward reports a finished stage: its gradient ranges go to the reducer; after the LAST encoder layer - only the front end is
+        still in backward - Adafactor's statistics pass over everything but the front-end tensors starts on the optimizer's second stream
+        (their gradients are final, and reduced once the comm stream has run; SMX_OPT_OVERLAP)."""
+        self.reducer.stage_done(name)
+        if name == "enc_layer0" and self._early_ok:
+            self._early_ok = False
+            st = self.store
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream()
+            lr = float(self.lr(self.t + 1)) if callable(self.lr) else float(self.lr)
+            clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
+            dropped = set(self.engine.last_dropped) if self.world == 1 else set()
+            active = [f and (l not in dropped) for f, l in zip((st.requires_grad(nm) for nm in self.af_names), self._af_layer)]
+            sh = None if st.shadow is st.master else st.shadow
+            o, nact = self.af.prepare(st.master, st.grad, sh, lr, active=active, grad_scale=1.0 / self.world, max_grad_norm=clip)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._opt_stream.wait_event(ev)
+            if self.reducer.comm_stream is not None:
+                self._opt_stream.wait_stream(self.reducer.comm_stream)
+            with torch.cuda.stream(self._opt_stream):
+                self.af.early_stats(o, self._af_split)
+            self._af_early = (o, nact, lr)
+
     def sync_params(self):
         """Make the current stream wait for an optimizer tail that is still running on the second stream (anything that reads parameters
         outside Engine.forward - a checkpoint, an evaluation loop of another object - calls this or synchronises the device)."""
@@ -242,6 +269,9 @@ class StepRunner:
         text = text_input_ids.to(st.device).contiguous() if (text_input_ids is not None and m._uses_text_ids) else None
         training = m.training and m.encoder_model.training
         fwd_kw = dict(training=training, weighted_sum=m.weighted_sum, lm_training=m._lm_training(), want_logits=False)
+        self._af_early = None
+        self._early_ok = (self.af is not None and getattr(self, "_af_split", None) is not None and ga == 1
+                          and os.environ.get("SMX_OPT_EARLY_STATS", "0") == "1")          # (off: measured slower, profiles/r06_probes_not_kept.txt item 6)
         G = self._step_graphs(wave, decoder_input_ids, labels, text, fwd_kw)
         trial = self._graph_trial if getattr(self, "_trial_mode", None) else None          # (steps that are eager for another reason are not samples)
         if trial is not None:
@@ -282,8 +312,13 @@ class StepRunner:
             if self._af_split is not None:
                 if self._opt_stream is None:
                     self._opt_stream = torch.cuda.Stream()
-                eng.param_event = self.af.step(st.master, st.grad, sh, lr, active=active, grad_scale=inv_world, max_grad_norm=clip,
-                                               split=self._af_split, tail_stream=self._opt_stream)
+                early, self._af_early = self._af_early, None
+                if early is not None:          # (the statistics of everything but the front end are already running: _stage_cb)
+                    early[0].lr = lr
+                    eng.param_event = self.af.finish(early[0], early[1], self._af_split, self._opt_stream, early=True)
+                else:
+                    eng.param_event = self.af.step(st.master, st.grad, sh, lr, active=active, grad_scale=inv_world, max_grad_norm=clip,
+                                                   split=self._af_split, tail_stream=self._opt_stream)
             else:
                 self.af.step(st.master, st.grad, sh, lr, active=active,
                              grad_scale=inv_world, max_grad_norm=clip)

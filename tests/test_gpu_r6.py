@@ -326,9 +326,10 @@ def test_optimizer_tail_beside_the_next_front_end_changes_no_bit():
             n *= d
         offs.append((off, sh))
         off = (off + n + 63) // 64 * 64
-    plans = [ops.AdafactorPlan(offs, dev) for _ in range(2)]
-    p = [torch.randn(off, device=dev) * 0.1 for _ in range(2)]
+    plans = [ops.AdafactorPlan(offs, dev) for _ in range(3)]
+    p = [torch.randn(off, device=dev) * 0.1 for _ in range(3)]
     p[1].copy_(p[0])
+    p[2].copy_(p[0])
     sh16 = [x.bfloat16() for x in p]
     side = torch.cuda.Stream()
     active = [True] * len(shapes)
@@ -339,9 +340,20 @@ def test_optimizer_tail_beside_the_next_front_end_changes_no_bit():
         done = plans[1].step(p[1], g, sh16[1], 1e-2, active=active, max_grad_norm=1.0, split=(2, 6), tail_stream=side)
         assert done is not None
         torch.cuda.current_stream().wait_event(done)
+        # third form: the statistics of everything outside the range taken EARLY on the second stream (the trainer starts them when the last
+        # encoder layer's gradients are final), the rest as above
+        o, nact = plans[2].prepare(p[2], g, sh16[2], 1e-2, active=active, max_grad_norm=1.0)
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            plans[2].early_stats(o, (2, 6))
+        done2 = plans[2].finish(o, nact, (2, 6), side, early=True)
+        torch.cuda.current_stream().wait_event(done2)
         torch.cuda.synchronize()
-        assert torch.equal(p[0], p[1]) and torch.equal(sh16[0], sh16[1]), step
-        assert torch.equal(plans[0].row, plans[1].row) and torch.equal(plans[0].col, plans[1].col) and torch.equal(plans[0].rmean, plans[1].rmean)
+        for k in (1, 2):
+            assert torch.equal(p[0], p[k]) and torch.equal(sh16[0], sh16[k]), (step, k)
+            assert torch.equal(plans[0].row, plans[k].row) and torch.equal(plans[0].col, plans[k].col) and torch.equal(plans[0].rmean, plans[k].rmean)
     assert plans[1].tile0_of(0) == 0 and plans[1].tile0_of(len(shapes)) == plans[1].ntiles
 
     # (b) through the runner
