@@ -223,7 +223,7 @@ class StepRunner:
             self._early_ok = False
             st = self.store
             if self._opt_stream is None:
-                self._opt_stream = torch.cuda.Stream()
+                self._opt_stream = torch.cuda.Stream()          # (torch's priority range here is (0, -1): there is no priority below the default)
             lr = float(self.lr(self.t + 1)) if callable(self.lr) else float(self.lr)
             clip = self.max_grad_norm if self.max_grad_norm and self.max_grad_norm > 0 else 0.0
             dropped = set(self.engine.last_dropped) if self.world == 1 else set()
@@ -311,7 +311,7 @@ class StepRunner:
             active = [f and (l not in dropped) for f, l in zip((st.requires_grad(nm) for nm in self.af_names), self._af_layer)]
             if self._af_split is not None:
                 if self._opt_stream is None:
-                    self._opt_stream = torch.cuda.Stream()
+                    self._opt_stream = torch.cuda.Stream()          # (torch's priority range here is (0, -1): there is no priority below the default)
                 early, self._af_early = self._af_early, None
                 if early is not None:          # (the statistics of everything but the front end are already running: _stage_cb)
                     early[0].lr = lr
