@@ -1,7 +1,7 @@
 """In-process A/B of run-time switches on config 2 (train mode, eager steps): ONE model and runner, the settings alternate in blocks of steps, so
 clock / box state is shared (process-level A/Bs of bench.py differ by up to 1 ms between identical configurations on some boxes).
     python tools/gpu_inproc_ab.py NAME [blocks] [steps_per_block]
-NAME: attn_v3 (SMX_ATTN_V3 0 / bwd / 1) | dgrad_wt (engine.WT_MODE off / on) | lm_defer ..."""
+NAME: attn_v3 | dgrad_wt | wgrad_side | lm_stream | colsum_side | pregen | head_side (see MODES)"""
 import contextlib, io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("SMX_STEP_GRAPHS", "0")
@@ -30,7 +30,12 @@ def attr(mod, k, v):
 
 
 MODES = {"attn_v3": [("v2 (SMX_ATTN_V3=0)", env("SMX_ATTN_V3", "0")), ("v3 backward (default)", env("SMX_ATTN_V3", "bwd")), ("v3 forward + backward", env("SMX_ATTN_V3", "1"))],
-         "dgrad_wt": [("rows-contiguous weight reads (default)", attr(E, "WT_MODE", False)), ("K-contiguous weight copies", attr(E, "WT_MODE", True))]}[name]
+         "dgrad_wt": [("rows-contiguous weight reads (default)", attr(E, "WT_MODE", False)), ("K-contiguous weight copies", attr(E, "WT_MODE", True))],
+         "wgrad_side": [("grouped weight gradients on the compute stream (default)", env("SMX_WGRAD_SIDE", "0")), ("on a second stream, joined a layer later", env("SMX_WGRAD_SIDE", "1"))],
+         "lm_stream": [("LM weight gradients on a second stream (default)", env("SMX_LM_WGRAD_STREAM", "1")), ("on the compute stream", env("SMX_LM_WGRAD_STREAM", "0"))],
+         "colsum_side": [("column sums beside the grouped launch (default)", attr(E, "_COLSUM_SIDE", True)), ("in the data-gradient chain", attr(E, "_COLSUM_SIDE", False))],
+         "pregen": [("attention masks generated beside the optimizer (default)", env("SMX_PREGEN_MASKS", "1")), ("generated in place", env("SMX_PREGEN_MASKS", "0"))],
+         "head_side": [("LM head weight gradient on the second stream (default)", env("SMX_HEAD_WGRAD_SIDE", "1")), ("on the compute stream", env("SMX_HEAD_WGRAD_SIDE", "0"))]}[name]
 dev = torch.device("cuda:0")
 with contextlib.redirect_stdout(io.StringIO()):
     model = SpeechMixEED("facebook/wav2vec2-base", "facebook/bart-base", share_layer_ratio=0, down_scale=2, compute_dtype="bf16", init_seed=0).train()
